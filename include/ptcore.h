@@ -1,0 +1,236 @@
+/*
+ * ptcore.h -- C ABI of the MI355X (gfx950) path-tracing core.
+ *
+ * This is the drop-in boundary for the per-pixel hot path of the reference
+ * renderer: everything OptiXRenderer/Renderer.cpp does to its OptiX context
+ * (create, upload Config / Triangle[] / Sphere[] / lights, pick the integrator,
+ * build the acceleration structure, launch, map the float3 result) has one
+ * entry point here.  All signatures are plain C: pointers, sizes and PODs.
+ *
+ * Conventions
+ *   - every call returns PTC_OK (0) or a negative PTC_ERR_* code;
+ *     ptc_last_error(ctx) returns a NUL-terminated message owned by the context
+ *     (ptc_last_error(NULL) returns the message of the last failed ptc_create);
+ *   - host arrays passed in are copied during the call, the caller keeps
+ *     ownership; output buffers are allocated by the caller;
+ *   - one context = one GPU = one caller thread at a time.  Multi-GPU runs use
+ *     one context per device (one per process/rank, or one per host thread);
+ *   - the POD layouts below are the wire format of the reference's own structs
+ *     (OptiXRenderer/Geometries.h, Light.h, Config.h) and are size/offset
+ *     checked at compile time in C++ translation units.
+ */
+#ifndef PTCORE_H
+#define PTCORE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ PODs -- */
+
+typedef struct PtcFloat3 { float x, y, z; } PtcFloat3;
+
+/* 8-byte aligned like CUDA's float2, so that PtcConfig has the same size (88)
+ * and offsets as the reference's Config under the OptiX/CUDA headers. */
+#if defined(__cplusplus)
+typedef struct alignas(8) PtcFloat2 { float x, y; } PtcFloat2;
+#else
+typedef struct PtcFloat2 { _Alignas(8) float x; float y; } PtcFloat2;
+#endif
+
+/* Geometries.h:10-14 */
+enum { PTC_OBJECT = 0, PTC_LIGHT = 1 };                     /* objectType   */
+enum { PTC_MOD_PHONG = 0, PTC_GGX = 1 };                    /* brdfType     */
+enum { PTC_DIFFUSE = 0, PTC_GLASS = 1, PTC_VOLUMETRIC = 2 };/* materialType */
+/* Config.h:5-7 */
+enum { PTC_HEMISPHERE_SAMPLING = 0, PTC_COSINE_SAMPLING = 1, PTC_BRDF_SAMPLING = 2 };
+enum { PTC_NEE_OFF = 0, PTC_NEE_ON = 1, PTC_NEE_MIS = 2 };
+
+/* Geometries.h:16-24 -- 84 bytes */
+typedef struct PtcMaterialValue {
+    PtcFloat3 ambient, diffuse, specular, emission;
+    float     shininess, roughness;
+    int32_t   brdf_type;
+    float     ior;
+    int32_t   matType;
+    float     sigma_a, sigma_s, sigma_t, g;
+} PtcMaterialValue;
+
+/* Geometries.h:26-31 -- 136 bytes */
+typedef struct PtcTriangle {
+    PtcFloat3        v1, v2, v3, normal;
+    PtcMaterialValue mv;
+    int32_t          objType;
+} PtcTriangle;
+
+/* Geometries.h:33-38 -- 152 bytes; trans is row-major, translation in
+ * elements [3], [7], [11] (Sphere.cu:67-69). */
+typedef struct PtcSphere {
+    float            trans[16];
+    PtcMaterialValue mv;
+    int32_t          objType;
+} PtcSphere;
+
+/* Light.h:10-26 */
+typedef struct PtcPointLight       { PtcFloat3 color, attenuation, location; } PtcPointLight;
+typedef struct PtcDirectionalLight { PtcFloat3 color, direction; }             PtcDirectionalLight;
+typedef struct PtcQuadLight        { PtcTriangle tri1, tri2; PtcFloat3 color; } PtcQuadLight;
+
+/* Config.h:9-36 -- 88 bytes */
+typedef struct PtcConfig {
+    PtcFloat3 w, u, v, eye;
+    PtcFloat2 hSize, tanHFov;
+    float     gamma;
+    uint32_t  maxDepth;
+    uint32_t  next_event_est;
+    float     epsilon;
+    uint32_t  russian_roul;
+} PtcConfig;
+
+/* Primary-hit record used by the parity checks: the closest hit of the
+ * pixel-centre ray (sample 0) of each pixel.  prim is the global primitive
+ * index (triangles 0..T-1 in upload order, then spheres T..T+S-1), -1 = miss.
+ * u,v are the barycentric weights of Triangle.cu:43-44 (u weighs v3, v weighs
+ * v2); 0 for spheres. */
+typedef struct PtcHitRecord { int32_t prim; float t, u, v; } PtcHitRecord;
+
+/* Counters and timings of the work done since the last ptc_reset_stats. */
+typedef struct PtcStats {
+    uint64_t paths;            /* camera paths started                         */
+    uint64_t extension_rays;   /* radiance segments traced (paths x bounces)   */
+    uint64_t shadow_rays;      /* shadow rays traced                           */
+    uint64_t extend_launches, connect_launches, shade_launches;
+    double   extend_ms, connect_ms, shade_ms, other_ms; /* HIP-event time, only with PTC_OPT_PROFILE */
+    uint64_t nodes_visited, prims_tested;               /* extension rays, only with PTC_OPT_COUNT_TRAVERSAL */
+    uint64_t shadow_nodes_visited, shadow_prims_tested; /* shadow rays, same option                          */
+    uint32_t bvh_nodes, bvh_max_depth;
+    double   build_ms;
+} PtcStats;
+
+typedef struct ptc_context ptc_context;
+
+/* ----------------------------------------------------------- error codes -- */
+enum {
+    PTC_OK = 0,
+    PTC_ERR_INVALID      = -1,  /* bad argument / call order                   */
+    PTC_ERR_INTEGRATOR   = -2,  /* unknown integrator name                     */
+    PTC_ERR_DEVICE       = -3,  /* HIP error (message has the HIP string)      */
+    PTC_ERR_UNSUPPORTED  = -4,  /* scene uses a feature outside the built path */
+    PTC_ERR_NOT_BUILT    = -5   /* render before ptc_build                     */
+};
+
+/* ---------------------------------------------------------------- options -- */
+enum {
+    /* 0 = literal: what the committed RayTracer.cu computes (computePolarAngles,
+     *     genCoordFrame, swapValue, samplePhaseHG take their outputs by value,
+     *     RayTracer.cu:232,296,302,337, so the callers' theta/phi/u/v stay 0).
+     * 1 = intended: the same code with those four outputs taken by reference. */
+    PTC_OPT_SEMANTICS = 1,
+    /* 0 = reference seeding: per-segment seed tea<16>(index*frameID, i++) with i
+     *     running over all segments of all earlier samples of the pixel
+     *     (PinholeCamera.cu:34,56); samples of a pixel are traced one at a time.
+     * 1 = counter seeding: seed(pixel,sample j,bounce b) =
+     *     tea<16>(index*frameID, (j<<12)|b); independent of how samples are
+     *     partitioned over batches or GPUs.  Identical to 0 for sample 0. */
+    PTC_OPT_SEEDING = 2,
+    /* Upper bound on segments per path, applied as min(Config.maxDepth, cap);
+     * 1..4096.  `maxdepth -1` parses to 0xFFFFFFFF (SceneLoader.cpp:98), which
+     * the reference would iterate literally. Default 1024. */
+    PTC_OPT_BOUNCE_CAP = 3,
+    /* 1 = stop a path once its throughput is exactly (0,0,0) (every later
+     * contribution is radiance*throughput, RayTracer.cu:918). Default 1. */
+    PTC_OPT_CULL_ZERO = 4,
+    /* Maximum camera paths in flight per wavefront batch (rounded to whole
+     * samples over the image). Default 8388608. */
+    PTC_OPT_BATCH_PATHS = 5,
+    /* 1 = bracket every kernel class with HIP events and sum the times. */
+    PTC_OPT_PROFILE = 6,
+    /* 1 = count BVH nodes visited / primitives tested per ray (slower). */
+    PTC_OPT_COUNT_TRAVERSAL = 7,
+    /* 0 = BVH traversal, 1 = brute force over all primitives (parity aid). */
+    PTC_OPT_BRUTE_FORCE = 8
+};
+
+/* ----------------------------------------------------------- entry points -- */
+
+/* Renderer.cpp:8-14 (Context::create, ray types, entry point). */
+int  ptc_create(int device_ordinal, ptc_context** out);
+int  ptc_destroy(ptc_context* ctx);
+const char* ptc_last_error(const ptc_context* ctx);
+
+/* Renderer.cpp:147-149 (config buffer). */
+int  ptc_set_config(ptc_context* ctx, const PtcConfig* cfg);
+/* Renderer.cpp:73,152-158: one of raytracer, analyticdirect, direct,
+ * pathtracer, pathtracer2; anything else -> PTC_ERR_INTEGRATOR with the message
+ * "Doesn't support the integrator <name>". */
+int  ptc_set_integrator(ptc_context* ctx, const char* name);
+/* Renderer.cpp:160-167 (integrator variables + samples_per_pixel). */
+int  ptc_set_params(ptc_context* ctx, uint32_t light_samples, uint32_t light_stratify,
+                    uint32_t next_event_est, uint32_t sampling_method, int32_t samples_per_pixel);
+/* Renderer.cpp:115-125,174-180 (RT_FORMAT_USER buffers of the AoS PODs). */
+int  ptc_set_triangles(ptc_context* ctx, const PtcTriangle* tris, size_t n);
+int  ptc_set_spheres(ptc_context* ctx, const PtcSphere* spheres, size_t n);
+/* Renderer.cpp:221-223. */
+int  ptc_set_lights(ptc_context* ctx,
+                    const PtcPointLight* pl, size_t n_point,
+                    const PtcDirectionalLight* dl, size_t n_directional,
+                    const PtcQuadLight* ql, size_t n_quad);
+/* Renderer.cpp:47 (miss program's backgroundColor). */
+int  ptc_set_background(ptc_context* ctx, float r, float g, float b);
+/* Renderer.cpp:182-217,226: primitive bounds (Triangle.cu:62-72,
+ * Sphere.cu:60-73) -> BVH built on the GPU. */
+int  ptc_build(ptc_context* ctx);
+/* Renderer.cpp:32-33: frameID + launch(0, width, height), synchronous. Renders
+ * samples [0, samples_per_pixel), then averages and gamma-corrects
+ * (PinholeCamera.cu:70-80). */
+int  ptc_render(ptc_context* ctx, int frame_id, uint32_t width, uint32_t height);
+/* Build-only: accumulate samples [spp_begin, spp_end) into the pre-gamma sum
+ * buffer (cleared first when clear != 0) without resolving; asynchronous on the
+ * context's stream. Used for the samples-per-pixel split across GPUs. */
+int  ptc_render_range(ptc_context* ctx, int frame_id, uint32_t width, uint32_t height,
+                      int32_t spp_begin, int32_t spp_end, int clear);
+/* Build-only: result = pow(sum / total_spp, 1/gamma) (frame 1) or the frame
+ * lerp of PinholeCamera.cu:75-80. */
+int  ptc_resolve(ptc_context* ctx, int frame_id, int32_t total_spp);
+/* Build-only parity dump: closest hit of every pixel's sample-0 ray,
+ * out[y*width + x]. */
+int  ptc_primary_hits(ptc_context* ctx, uint32_t width, uint32_t height, PtcHitRecord* out);
+/* Renderer.cpp:85,103 (map/unmap): width*height*3 floats, element (x,y) at
+ * (y*width + x)*3, row 0 at the bottom. */
+int  ptc_read_result(ptc_context* ctx, float* rgb_out);
+/* Build-only: the pre-gamma radiance sums, same indexing. */
+int  ptc_read_sum(ptc_context* ctx, float* rgb_out);
+/* Build-only: let the caller own the device memory of the radiance sums
+ * (width*height*3 floats), e.g. a tensor that a collective then reduces.
+ * NULL returns to the context's own buffer. */
+int  ptc_bind_sum_buffer(ptc_context* ctx, void* device_ptr, size_t bytes);
+/* Build-only: run on the caller's HIP stream (hipStream_t as void*). */
+int  ptc_set_stream(ptc_context* ctx, void* hip_stream);
+int  ptc_synchronize(ptc_context* ctx);
+
+int  ptc_set_option(ptc_context* ctx, int option, int64_t value);
+int  ptc_get_stats(ptc_context* ctx, PtcStats* out);
+int  ptc_reset_stats(ptc_context* ctx);
+
+#ifdef __cplusplus
+} /* extern "C" */
+
+static_assert(sizeof(PtcFloat3) == 12, "float3");
+static_assert(sizeof(PtcMaterialValue) == 84, "MaterialValue is 84 bytes");
+static_assert(offsetof(PtcMaterialValue, shininess) == 48, "MaterialValue.shininess");
+static_assert(offsetof(PtcMaterialValue, matType) == 64, "MaterialValue.matType");
+static_assert(sizeof(PtcTriangle) == 136 && offsetof(PtcTriangle, mv) == 48 &&
+              offsetof(PtcTriangle, objType) == 132, "Triangle is 136 bytes");
+static_assert(sizeof(PtcSphere) == 152 && offsetof(PtcSphere, mv) == 64 &&
+              offsetof(PtcSphere, objType) == 148, "Sphere is 152 bytes");
+static_assert(sizeof(PtcQuadLight) == 284 && offsetof(PtcQuadLight, color) == 272, "QuadLight is 284 bytes");
+static_assert(sizeof(PtcPointLight) == 36 && sizeof(PtcDirectionalLight) == 24, "lights");
+static_assert(sizeof(PtcConfig) == 88 && offsetof(PtcConfig, hSize) == 48 &&
+              offsetof(PtcConfig, gamma) == 64 && offsetof(PtcConfig, russian_roul) == 80, "Config is 88 bytes");
+static_assert(sizeof(PtcHitRecord) == 16, "HitRecord");
+#endif
+
+#endif /* PTCORE_H */
