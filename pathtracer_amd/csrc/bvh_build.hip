@@ -1,0 +1,533 @@
+// bvh_build.hip -- acceleration-structure build on the GPU.
+//
+// Stands in for the three closed-source "Trbvh" builds of the reference
+// (Renderer.cpp:202-217).  Primitive boxes come from the reference's bounding
+// programs (Triangle.cu:62-72, Sphere.cu:60-73).  Per primitive kind:
+//   1. primitive boxes                                   (k_bounds_*)
+//   2. primitives much larger than the rest of the scene (a ground plane under
+//      a detailed mesh) go into one top-level leaf instead of the tree: a
+//      Morton-ordered tree would otherwise inflate every ancestor box
+//   3. 63-bit Morton codes of the remaining centroids, radix sort (rocPRIM)
+//   4. Karras' binary radix tree, one thread per internal node
+//   5. bottom-up boxes, one launch per tree level (no intra-launch hand-off)
+//   6. subtrees of <= BVH_LEAF_MAX primitives collapse into leaves; the kept
+//      nodes are renumbered densely and written as 64-byte two-box nodes
+// Triangles are repacked into leaf order as 3 x float4.  Every box is padded by
+// a few dozen ulps of the scene's largest coordinate so that the box test can
+// never reject a primitive the exact primitive test would accept.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include <rocprim/rocprim.hpp>
+
+#include "wavefront.h"
+
+#define BB 256
+#define HIPCHK(x)                                                                        \
+    do {                                                                                 \
+        hipError_t e_ = (x);                                                             \
+        if (e_ != hipSuccess) return std::string(#x) + ": " + hipGetErrorString(e_);     \
+    } while (0)
+
+namespace {
+
+struct Box6 {
+    float lo[3], hi[3];
+};
+
+__global__ void k_bounds_tri(const PtcTriangle* __restrict__ tris, uint32_t n, Box6* __restrict__ out) {
+    const uint32_t i = blockIdx.x * BB + threadIdx.x;
+    if (i >= n) return;
+    const PtcTriangle& t = tris[i];
+    Box6 b;  // Triangle.cu:66-71
+    b.lo[0] = fminf(fminf(t.v1.x, t.v2.x), t.v3.x);
+    b.lo[1] = fminf(fminf(t.v1.y, t.v2.y), t.v3.y);
+    b.lo[2] = fminf(fminf(t.v1.z, t.v2.z), t.v3.z);
+    b.hi[0] = fmaxf(fmaxf(t.v1.x, t.v2.x), t.v3.x);
+    b.hi[1] = fmaxf(fmaxf(t.v1.y, t.v2.y), t.v3.y);
+    b.hi[2] = fmaxf(fmaxf(t.v1.z, t.v2.z), t.v3.z);
+    out[i] = b;
+}
+
+__global__ void k_bounds_sphere(const PtcSphere* __restrict__ sph, uint32_t n, Box6* __restrict__ out) {
+    const uint32_t i = blockIdx.x * BB + threadIdx.x;
+    if (i >= n) return;
+    const float* m = sph[i].trans;  // Sphere.cu:63-72
+    const float x = length(mk3(m[0], m[1], m[2])), y = length(mk3(m[4], m[5], m[6])), z = length(mk3(m[8], m[9], m[10]));
+    Box6 b;
+    b.lo[0] = m[3] - x; b.lo[1] = m[7] - y; b.lo[2] = m[11] - z;
+    b.hi[0] = m[3] + x; b.hi[1] = m[7] + y; b.hi[2] = m[11] + z;
+    out[i] = b;
+}
+
+__device__ __forceinline__ uint64_t spread21(uint32_t v) {  // 21 bits -> every third bit
+    uint64_t x = v & 0x1FFFFFull;
+    x = (x | x << 32) & 0x1F00000000FFFFull;
+    x = (x | x << 16) & 0x1F0000FF0000FFull;
+    x = (x | x << 8) & 0x100F00F00F00F00Full;
+    x = (x | x << 4) & 0x10C30C30C30C30C3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+
+__global__ void k_morton(const Box6* __restrict__ boxes, const uint32_t* __restrict__ ids, uint32_t n, float3 cmin, float3 cinv,
+                         uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const uint32_t i = blockIdx.x * BB + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t prim = ids[i];
+    const Box6 b = boxes[prim];
+    const float cx = (0.5f * (b.lo[0] + b.hi[0]) - cmin.x) * cinv.x;
+    const float cy = (0.5f * (b.lo[1] + b.hi[1]) - cmin.y) * cinv.y;
+    const float cz = (0.5f * (b.lo[2] + b.hi[2]) - cmin.z) * cinv.z;
+    const float scale = 2097151.0f;  // 2^21 - 1
+    const uint32_t qx = (uint32_t)fminf(fmaxf(cx * scale, 0.f), scale);
+    const uint32_t qy = (uint32_t)fminf(fmaxf(cy * scale, 0.f), scale);
+    const uint32_t qz = (uint32_t)fminf(fmaxf(cz * scale, 0.f), scale);
+    keys[i] = (spread21(qx) << 2) | (spread21(qy) << 1) | spread21(qz);
+    vals[i] = prim;
+}
+
+// Length of the common prefix of keys i and j; equal keys are told apart by
+// their position so that the tree stays a proper binary tree.
+__device__ __forceinline__ int delta(const uint64_t* __restrict__ keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    const uint64_t a = keys[i], b = keys[j];
+    if (a == b) return 64 + __clz(i ^ j);
+    return __clzll((long long)(a ^ b));
+}
+
+// Tree arrays: internal nodes 0..n-2, leaves addressed as n-1+leaf in `parent`
+// and as (leaf | LEAF_FLAG) in the child arrays.
+#define LEAF_FLAG 0x80000000u
+
+__global__ void k_karras(const uint64_t* __restrict__ keys, int n, uint32_t* __restrict__ left, uint32_t* __restrict__ right,
+                         int* __restrict__ first, int* __restrict__ last, int* __restrict__ parent) {
+    const int i = blockIdx.x * BB + threadIdx.x;
+    if (i >= n - 1) return;
+    const int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+    const int dmin = delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (delta(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2)
+        if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = delta(keys, n, i, j);
+    int s = 0, t = l;
+    do {
+        t = (t + 1) / 2;
+        if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    const int gamma = i + s * d + min(d, 0);
+    const int lo = min(i, j), hi = max(i, j);
+    first[i] = lo;
+    last[i] = hi;
+    if (lo == gamma) {
+        left[i] = (uint32_t)gamma | LEAF_FLAG;
+        parent[n - 1 + gamma] = i;
+    } else {
+        left[i] = (uint32_t)gamma;
+        parent[gamma] = i;
+    }
+    if (hi == gamma + 1) {
+        right[i] = (uint32_t)(gamma + 1) | LEAF_FLAG;
+        parent[n - 1 + gamma + 1] = i;
+    } else {
+        right[i] = (uint32_t)(gamma + 1);
+        parent[gamma + 1] = i;
+    }
+    if (i == 0) parent[0] = -1;
+}
+
+__global__ void k_leaf_boxes(const Box6* __restrict__ boxes, const uint32_t* __restrict__ sorted_prims, int n, float pad, Box6* __restrict__ node_box /* [2n-1] */) {
+    const int i = blockIdx.x * BB + threadIdx.x;
+    if (i >= n) return;
+    Box6 b = boxes[sorted_prims[i]];
+    for (int k = 0; k < 3; ++k) {
+        b.lo[k] -= pad;
+        b.hi[k] += pad;
+    }
+    node_box[n - 1 + i] = b;
+}
+
+__global__ void k_depth(const int* __restrict__ parent, int n, uint32_t* __restrict__ max_depth) {
+    const int i = blockIdx.x * BB + threadIdx.x;
+    if (i >= n) return;
+    uint32_t d = 0;
+    int cur = parent[n - 1 + i];
+    while (cur >= 0 && d < 4096u) {
+        ++d;
+        cur = parent[cur];
+    }
+    atomicMax(max_depth, d);
+}
+
+// One level of the bottom-up box pass: a node is finished in pass `pass` when both
+// children were finished in an earlier pass (done[] holds the finishing pass, 0 = not
+// yet; leaves count as finished before pass 1).
+__global__ void k_refit_pass(const uint32_t* __restrict__ left, const uint32_t* __restrict__ right, int n, int pass, int* __restrict__ done,
+                             Box6* __restrict__ node_box) {
+    const int i = blockIdx.x * BB + threadIdx.x;
+    if (i >= n - 1) return;
+    if (done[i] != 0) return;
+    const uint32_t l = left[i], r = right[i];
+    const bool lready = (l & LEAF_FLAG) || (done[l] != 0 && done[l] < pass);
+    const bool rready = (r & LEAF_FLAG) || (done[r] != 0 && done[r] < pass);
+    if (!lready || !rready) return;
+    const Box6 a = node_box[(l & LEAF_FLAG) ? n - 1 + (int)(l & ~LEAF_FLAG) : (int)l];
+    const Box6 b = node_box[(r & LEAF_FLAG) ? n - 1 + (int)(r & ~LEAF_FLAG) : (int)r];
+    Box6 u;
+    for (int k = 0; k < 3; ++k) {
+        u.lo[k] = fminf(a.lo[k], b.lo[k]);
+        u.hi[k] = fmaxf(a.hi[k], b.hi[k]);
+    }
+    node_box[i] = u;
+    done[i] = pass;
+}
+
+__global__ void k_emit(const uint32_t* __restrict__ left, const uint32_t* __restrict__ right, const int* __restrict__ first, const int* __restrict__ last,
+                       const int* __restrict__ newidx /* -1 = collapsed */, const Box6* __restrict__ node_box, int n, uint32_t node_base, uint32_t kind,
+                       BvhNode* __restrict__ nodes) {
+    const int i = blockIdx.x * BB + threadIdx.x;
+    if (i >= n - 1) return;
+    if (newidx[i] < 0) return;
+    BvhNode out;
+    const uint32_t ch[2] = {left[i], right[i]};
+    for (int c = 0; c < 2; ++c) {
+        const uint32_t r = ch[c];
+        Box6 b;
+        uint32_t ref;
+        if (r & LEAF_FLAG) {
+            const int leaf = (int)(r & ~LEAF_FLAG);
+            b = node_box[n - 1 + leaf];
+            ref = MAKE_LEAF(kind, leaf, 1u);
+        } else {
+            b = node_box[r];
+            if (newidx[r] >= 0) ref = node_base + (uint32_t)newidx[r];
+            else ref = MAKE_LEAF(kind, first[r], (uint32_t)(last[r] - first[r] + 1));
+        }
+        float* lo = c == 0 ? out.lo0 : out.lo1;
+        float* hi = c == 0 ? out.hi0 : out.hi1;
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = b.lo[k];
+            hi[k] = b.hi[k];
+        }
+        out.child[c] = ref;
+    }
+    out.pad[0] = out.pad[1] = 0u;
+    nodes[node_base + (uint32_t)newidx[i]] = out;
+}
+
+__global__ void k_pack_tris(const PtcTriangle* __restrict__ tris, const int32_t* __restrict__ slot_prim, uint32_t n, float4* __restrict__ tri_q) {
+    const uint32_t s = blockIdx.x * BB + threadIdx.x;
+    if (s >= n) return;
+    const PtcTriangle& t = tris[slot_prim[s]];
+    tri_q[3 * (size_t)s + 0] = make_float4(t.v1.x, t.v1.y, t.v1.z, t.normal.x);
+    tri_q[3 * (size_t)s + 1] = make_float4(t.v2.x, t.v2.y, t.v2.z, t.normal.y);
+    tri_q[3 * (size_t)s + 2] = make_float4(t.v3.x, t.v3.y, t.v3.z, t.normal.z);
+}
+
+inline uint32_t nblocks(size_t n) { return (uint32_t)((n + BB - 1) / BB); }
+
+float maxExtent(const Box6& b) { return std::max(b.hi[0] - b.lo[0], std::max(b.hi[1] - b.lo[1], b.hi[2] - b.lo[2])); }
+
+Box6 emptyBox() {
+    Box6 b;
+    for (int k = 0; k < 3; ++k) {
+        b.lo[k] = INFINITY;
+        b.hi[k] = -INFINITY;
+    }
+    return b;
+}
+void grow(Box6& a, const Box6& b) {
+    for (int k = 0; k < 3; ++k) {
+        a.lo[k] = std::min(a.lo[k], b.lo[k]);
+        a.hi[k] = std::max(a.hi[k], b.hi[k]);
+    }
+}
+
+// Split the primitives of one kind into "small" (tree) and "big" (top-level leaf).
+void classify(const std::vector<Box6>& boxes, std::vector<uint32_t>& small, std::vector<uint32_t>& big) {
+    const size_t n = boxes.size();
+    small.clear();
+    big.clear();
+    if (n <= BVH_BIG_MAX) {
+        for (uint32_t i = 0; i < n; ++i) big.push_back(i);
+        return;
+    }
+    std::vector<char> isBig(n, 0);
+    for (int round = 0; round < 4; ++round) {
+        Box6 u = emptyBox();
+        for (size_t i = 0; i < n; ++i)
+            if (!isBig[i]) grow(u, boxes[i]);
+        const float E = maxExtent(u);
+        std::vector<uint32_t> cand;
+        for (uint32_t i = 0; i < n; ++i)
+            if (!isBig[i] && maxExtent(boxes[i]) > 0.5f * E) cand.push_back(i);
+        if (cand.empty()) break;
+        // at most BVH_BIG_MAX in total, largest first; never empty the small set
+        std::sort(cand.begin(), cand.end(), [&](uint32_t a, uint32_t b) { return maxExtent(boxes[a]) > maxExtent(boxes[b]); });
+        size_t nbig = 0;
+        for (char c : isBig) nbig += c;
+        bool added = false;
+        for (uint32_t c : cand) {
+            if (nbig >= BVH_BIG_MAX) break;
+            isBig[c] = 1;
+            ++nbig;
+            added = true;
+        }
+        if (!added || nbig >= BVH_BIG_MAX) break;
+    }
+    for (uint32_t i = 0; i < n; ++i) (isBig[i] ? big : small).push_back(i);
+}
+
+struct KindResult {
+    std::vector<int32_t> slot_prim;  // slot -> primitive index within its kind
+    uint32_t n_small = 0, n_big = 0;
+    uint32_t n_tree_nodes = 0;       // emitted nodes written at node_base..
+    bool has_tree = false;
+    Box6 tree_box, small_box, big_box;
+    uint32_t max_depth = 0;
+};
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t n) { return hipMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T)); }
+};
+
+// LBVH over the small primitives of one kind; writes emitted nodes to nodes[node_base..].
+std::string buildKind(hipStream_t s, const Box6* d_boxes, const std::vector<Box6>& boxes, uint32_t kind, float pad, BvhNode* d_nodes, uint32_t node_base,
+                      KindResult& res) {
+    std::vector<uint32_t> small, big;
+    classify(boxes, small, big);
+    res.n_small = (uint32_t)small.size();
+    res.n_big = (uint32_t)big.size();
+    res.small_box = emptyBox();
+    res.big_box = emptyBox();
+    auto padded = [&](Box6 b) {
+        for (int k = 0; k < 3; ++k) {
+            b.lo[k] -= pad;
+            b.hi[k] += pad;
+        }
+        return b;
+    };
+    for (uint32_t i : small) grow(res.small_box, padded(boxes[i]));
+    for (uint32_t i : big) grow(res.big_box, padded(boxes[i]));
+    const int n = (int)small.size();
+    res.slot_prim.clear();
+    if (n > BVH_LEAF_MAX) {
+        Box6 cb = emptyBox();
+        for (uint32_t i : small) {
+            Box6 c;
+            for (int k = 0; k < 3; ++k) c.lo[k] = c.hi[k] = 0.5f * (boxes[i].lo[k] + boxes[i].hi[k]);
+            grow(cb, c);
+        }
+        float3 cmin = make_float3(cb.lo[0], cb.lo[1], cb.lo[2]);
+        float3 cinv;
+        cinv.x = cb.hi[0] > cb.lo[0] ? 1.0f / (cb.hi[0] - cb.lo[0]) : 0.f;
+        cinv.y = cb.hi[1] > cb.lo[1] ? 1.0f / (cb.hi[1] - cb.lo[1]) : 0.f;
+        cinv.z = cb.hi[2] > cb.lo[2] ? 1.0f / (cb.hi[2] - cb.lo[2]) : 0.f;
+
+        DevBuf<uint32_t> ids, vals_in, vals_out, left, right;
+        DevBuf<uint64_t> keys_in, keys_out;
+        DevBuf<int> first, last, parent, done, newidx;
+        DevBuf<Box6> node_box;
+        DevBuf<uint32_t> depth;
+        HIPCHK(ids.alloc(n)); HIPCHK(vals_in.alloc(n)); HIPCHK(vals_out.alloc(n));
+        HIPCHK(keys_in.alloc(n)); HIPCHK(keys_out.alloc(n));
+        HIPCHK(left.alloc(n)); HIPCHK(right.alloc(n)); HIPCHK(first.alloc(n)); HIPCHK(last.alloc(n));
+        HIPCHK(parent.alloc(2 * (size_t)n)); HIPCHK(done.alloc(n)); HIPCHK(newidx.alloc(n));
+        HIPCHK(node_box.alloc(2 * (size_t)n)); HIPCHK(depth.alloc(1));
+        HIPCHK(hipMemcpyAsync(ids.p, small.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_morton, dim3(nblocks(n)), dim3(BB), 0, s, d_boxes, ids.p, (uint32_t)n, cmin, cinv, keys_in.p, vals_in.p);
+        size_t temp_bytes = 0;
+        HIPCHK(rocprim::radix_sort_pairs(nullptr, temp_bytes, keys_in.p, keys_out.p, vals_in.p, vals_out.p, (size_t)n, 0, 63, s));
+        DevBuf<char> temp;
+        HIPCHK(temp.alloc(temp_bytes));
+        HIPCHK(rocprim::radix_sort_pairs(temp.p, temp_bytes, keys_in.p, keys_out.p, vals_in.p, vals_out.p, (size_t)n, 0, 63, s));
+        hipLaunchKernelGGL(k_karras, dim3(nblocks(n - 1)), dim3(BB), 0, s, keys_out.p, n, left.p, right.p, first.p, last.p, parent.p);
+        hipLaunchKernelGGL(k_leaf_boxes, dim3(nblocks(n)), dim3(BB), 0, s, d_boxes, vals_out.p, n, pad, node_box.p);
+        HIPCHK(hipMemsetAsync(depth.p, 0, sizeof(uint32_t), s));
+        hipLaunchKernelGGL(k_depth, dim3(nblocks(n)), dim3(BB), 0, s, parent.p, n, depth.p);
+        uint32_t h_depth = 0;
+        HIPCHK(hipMemcpyAsync(&h_depth, depth.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (h_depth >= 4096u) return "BVH build: malformed radix tree";
+        res.max_depth = h_depth;
+        HIPCHK(hipMemsetAsync(done.p, 0, sizeof(int) * n, s));
+        for (int pass = 1; pass <= (int)h_depth + 1; ++pass)
+            hipLaunchKernelGGL(k_refit_pass, dim3(nblocks(n - 1)), dim3(BB), 0, s, left.p, right.p, n, pass, done.p, node_box.p);
+        // which internal nodes survive the leaf collapse, renumbered densely (root first)
+        std::vector<int> h_first(n - 1), h_last(n - 1), h_done(n - 1), h_new(n - 1);
+        std::vector<uint32_t> h_sorted(n);
+        HIPCHK(hipMemcpyAsync(h_first.data(), first.p, sizeof(int) * (n - 1), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(h_last.data(), last.p, sizeof(int) * (n - 1), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(h_done.data(), done.p, sizeof(int) * (n - 1), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(h_sorted.data(), vals_out.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, s));
+        Box6 rootBox;
+        HIPCHK(hipMemcpyAsync(&rootBox, node_box.p, sizeof(Box6), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        int emitted = 0;
+        for (int i = 0; i < n - 1; ++i) {
+            if (h_done[i] == 0) return "BVH build: box pass did not reach every node";
+            h_new[i] = (h_last[i] - h_first[i] + 1 > BVH_LEAF_MAX) ? emitted++ : -1;
+        }
+        HIPCHK(hipMemcpyAsync(newidx.p, h_new.data(), sizeof(int) * (n - 1), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_emit, dim3(nblocks(n - 1)), dim3(BB), 0, s, left.p, right.p, first.p, last.p, newidx.p, node_box.p, n, node_base, kind, d_nodes);
+        HIPCHK(hipStreamSynchronize(s));
+        res.n_tree_nodes = (uint32_t)emitted;
+        res.has_tree = true;
+        res.tree_box = rootBox;
+        for (int i = 0; i < n; ++i) res.slot_prim.push_back((int32_t)h_sorted[i]);
+    } else {
+        for (uint32_t i : small) res.slot_prim.push_back((int32_t)i);
+    }
+    for (uint32_t i : big) res.slot_prim.push_back((int32_t)i);
+    return "";
+}
+
+struct TopEntry {
+    uint32_t ref;
+    Box6 box;
+};
+
+void setChild(BvhNode& nd, int c, const TopEntry& e) {
+    float* lo = c == 0 ? nd.lo0 : nd.lo1;
+    float* hi = c == 0 ? nd.hi0 : nd.hi1;
+    for (int k = 0; k < 3; ++k) {
+        lo[k] = e.box.lo[k];
+        hi[k] = e.box.hi[k];
+    }
+    nd.child[c] = e.ref;
+}
+
+}  // namespace
+
+#define TOP_NODES 3u
+
+std::string bvh_build(hipStream_t s, const BvhBuildInput& in, BvhBuildOutput& out) {
+    const uint32_t T = in.n_tris, S = in.n_spheres;
+    // 1. primitive boxes
+    DevBuf<Box6> d_tbox, d_sbox;
+    HIPCHK(d_tbox.alloc(T));
+    HIPCHK(d_sbox.alloc(S));
+    if (T) hipLaunchKernelGGL(k_bounds_tri, dim3(nblocks(T)), dim3(BB), 0, s, in.d_tris, T, d_tbox.p);
+    if (S) hipLaunchKernelGGL(k_bounds_sphere, dim3(nblocks(S)), dim3(BB), 0, s, in.d_spheres, S, d_sbox.p);
+    std::vector<Box6> tbox(T), sbox(S);
+    if (T) HIPCHK(hipMemcpyAsync(tbox.data(), d_tbox.p, sizeof(Box6) * T, hipMemcpyDeviceToHost, s));
+    if (S) HIPCHK(hipMemcpyAsync(sbox.data(), d_sbox.p, sizeof(Box6) * S, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+
+    // 2. padding: a few dozen ulps of the largest coordinate a ray can start from or reach
+    float ext = in.extra_extent;
+    for (const auto* v : {&tbox, &sbox})
+        for (const Box6& b : *v)
+            for (int k = 0; k < 3; ++k) {
+                if (std::isfinite(b.lo[k])) ext = std::max(ext, fabsf(b.lo[k]));
+                if (std::isfinite(b.hi[k])) ext = std::max(ext, fabsf(b.hi[k]));
+            }
+    const float pad = 2e-6f * std::max(ext, 1.0f);
+
+    // 3. trees (node array: TOP_NODES top-level nodes, then the triangle tree, then the sphere tree)
+    const size_t max_nodes = TOP_NODES + (size_t)T + (size_t)S + 2;
+    HIPCHK(hipMalloc((void**)&out.nodes, max_nodes * sizeof(BvhNode)));
+    HIPCHK(hipMemsetAsync(out.nodes, 0, max_nodes * sizeof(BvhNode), s));
+    KindResult kt, ks;
+    std::string err = buildKind(s, d_tbox.p, tbox, REF_TRI, pad, out.nodes, TOP_NODES, kt);
+    if (!err.empty()) return err;
+    err = buildKind(s, d_sbox.p, sbox, REF_SPHERE, pad, out.nodes, TOP_NODES + kt.n_tree_nodes, ks);
+    if (!err.empty()) return err;
+    out.n_nodes = TOP_NODES + kt.n_tree_nodes + ks.n_tree_nodes;
+    out.max_depth = std::max(kt.max_depth, ks.max_depth) + 2u;
+    if (out.max_depth > TRAV_LDS_STACK + TRAV_SPILL_STACK) return "BVH too deep for the traversal stack";
+
+    // 4. top level
+    std::vector<TopEntry> entries;
+    auto addKind = [&](const KindResult& k, uint32_t kind, uint32_t base) {
+        if (k.has_tree) entries.push_back({base, k.tree_box});
+        else if (k.n_small) entries.push_back({MAKE_LEAF(kind, 0u, k.n_small), k.small_box});
+        if (k.n_big) entries.push_back({MAKE_LEAF(kind, k.n_small, k.n_big), k.big_box});
+    };
+    addKind(kt, REF_TRI, TOP_NODES);
+    addKind(ks, REF_SPHERE, TOP_NODES + kt.n_tree_nodes);
+    BvhNode top[TOP_NODES];
+    std::memset(top, 0, sizeof(top));
+    for (auto& nd : top) nd.child[0] = nd.child[1] = REF_EMPTY_WORD;
+    auto unionBox = [](const TopEntry& a, const TopEntry& b) {
+        Box6 u = a.box;
+        grow(u, b.box);
+        return u;
+    };
+    if (entries.empty()) {
+        out.n_nodes = 0;
+    } else if (entries.size() == 1) {
+        setChild(top[0], 0, entries[0]);
+    } else if (entries.size() == 2) {
+        setChild(top[0], 0, entries[0]);
+        setChild(top[0], 1, entries[1]);
+    } else if (entries.size() == 3) {
+        setChild(top[1], 0, entries[1]);
+        setChild(top[1], 1, entries[2]);
+        setChild(top[0], 0, entries[0]);
+        setChild(top[0], 1, TopEntry{1u, unionBox(entries[1], entries[2])});
+    } else {
+        setChild(top[1], 0, entries[0]);
+        setChild(top[1], 1, entries[1]);
+        setChild(top[2], 0, entries[2]);
+        setChild(top[2], 1, entries[3]);
+        setChild(top[0], 0, TopEntry{1u, unionBox(entries[0], entries[1])});
+        setChild(top[0], 1, TopEntry{2u, unionBox(entries[2], entries[3])});
+    }
+    HIPCHK(hipMemcpyAsync(out.nodes, top, sizeof(top), hipMemcpyHostToDevice, s));
+
+    // 5. geometry in leaf order
+    HIPCHK(hipMalloc((void**)&out.tri_q, std::max<size_t>(T, 1) * 3 * sizeof(float4)));
+    HIPCHK(hipMalloc((void**)&out.tri_mat, std::max<size_t>(T, 1) * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void**)&out.tri_prim, std::max<size_t>(T, 1) * sizeof(int32_t)));
+    HIPCHK(hipMalloc((void**)&out.spheres, std::max<size_t>(S, 1) * sizeof(DevSphere)));
+    HIPCHK(hipMalloc((void**)&out.sph_mat, std::max<size_t>(S, 1) * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void**)&out.sph_prim, std::max<size_t>(S, 1) * sizeof(int32_t)));
+    std::vector<uint32_t> tmat(T), smat(S);
+    std::vector<int32_t> sprim(S);
+    for (uint32_t i = 0; i < T; ++i) tmat[i] = in.h_tri_mat[kt.slot_prim[i]];
+    if (T) {
+        HIPCHK(hipMemcpyAsync(out.tri_prim, kt.slot_prim.data(), sizeof(int32_t) * T, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(out.tri_mat, tmat.data(), sizeof(uint32_t) * T, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_pack_tris, dim3(nblocks(T)), dim3(BB), 0, s, in.d_tris, out.tri_prim, T, out.tri_q);
+    }
+    std::vector<DevSphere> hs(S);
+    if (S) {
+        std::vector<PtcSphere> hsph(S);
+        HIPCHK(hipMemcpyAsync(hsph.data(), in.d_spheres, sizeof(PtcSphere) * S, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        for (uint32_t i = 0; i < S; ++i) {
+            const int32_t src = ks.slot_prim[i];
+            mat4 m;
+            std::memcpy(m.m, hsph[src].trans, sizeof(m.m));
+            const mat4 inv = mat4_inverse(m);
+            std::memcpy(hs[i].trans, m.m, sizeof(m.m));
+            std::memcpy(hs[i].itrans, inv.m, sizeof(inv.m));
+            smat[i] = in.h_sph_mat[src];
+            sprim[i] = (int32_t)T + src;  // global primitive index: triangles first
+        }
+        HIPCHK(hipMemcpyAsync(out.spheres, hs.data(), sizeof(DevSphere) * S, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(out.sph_mat, smat.data(), sizeof(uint32_t) * S, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(out.sph_prim, sprim.data(), sizeof(int32_t) * S, hipMemcpyHostToDevice, s));
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    return "";
+}
+
+void bvh_free(BvhBuildOutput& o) {
+    for (void* p : {(void*)o.tri_q, (void*)o.tri_mat, (void*)o.tri_prim, (void*)o.spheres, (void*)o.sph_mat, (void*)o.sph_prim, (void*)o.nodes})
+        if (p) (void)hipFree(p);
+    o = BvhBuildOutput();
+}

@@ -1,0 +1,117 @@
+// device_scene.h -- device-side data layout of the path-tracing core.
+//
+// The host hands over the reference's AoS PODs (136-byte Triangle with an
+// embedded 84-byte material, 152-byte Sphere).  On upload they are repacked:
+//   * triangle geometry  -> 3 x float4 per triangle in BVH leaf order
+//                           (v1|n.x, v2|n.y, v3|n.z): 48 bytes, one aligned
+//                           fetch per component, leaves contiguous;
+//   * materials          -> de-duplicated table, one 32-bit id per primitive
+//                           (bit 31 = objectType LIGHT);
+//   * spheres            -> transform + precomputed inverse (128 bytes);
+//   * BVH                -> 64-byte binary nodes holding BOTH child boxes.
+#pragma once
+
+#include <stdint.h>
+
+#include "ptcore.h"
+#include "ptmath.h"
+
+// ---- BVH node: 64 bytes, read as 4 x float4 ---------------------------------
+//   q0 = (lo0.x, lo0.y, lo0.z, hi0.x)
+//   q1 = (hi0.y, hi0.z, lo1.x, lo1.y)
+//   q2 = (lo1.z, hi1.x, hi1.y, hi1.z)
+//   q3 = (child0, child1, unused, unused)   [bit patterns]
+struct BvhNode {
+    float lo0[3], hi0[3];
+    float lo1[3], hi1[3];
+    uint32_t child[2];
+    uint32_t pad[2];
+};
+static_assert(sizeof(BvhNode) == 64, "BVH node is 64 bytes");
+
+// Child reference encoding.
+//   kind (bits 31..30): 0 internal node, 1 triangle leaf, 2 sphere leaf, 3 empty
+//   internal: bits 29..0 = node index
+//   leaf:     bits 29..27 = count-1 (1..8 primitives), bits 26..0 = first slot
+#define REF_KIND(r) ((r) >> 30)
+#define REF_INTERNAL 0u
+#define REF_TRI 1u
+#define REF_SPHERE 2u
+#define REF_EMPTY 3u
+#define REF_EMPTY_WORD 0xC0000000u
+#define REF_NODE(r) ((r)&0x3FFFFFFFu)
+#define REF_FIRST(r) ((r)&0x07FFFFFFu)
+#define REF_COUNT(r) ((((r) >> 27) & 7u) + 1u)
+#define MAKE_LEAF(kind, first, count) (((uint32_t)(kind) << 30) | ((uint32_t)((count)-1u) << 27) | (uint32_t)(first))
+#define BVH_LEAF_MAX 4  /* primitives per collapsed LBVH leaf */
+#define BVH_BIG_MAX 8   /* primitives per top-level "large primitive" leaf */
+
+// Traversal stack: entries per thread kept in LDS, further entries in per-thread
+// scratch; the build refuses trees deeper than their sum.
+#define TRAV_LDS_STACK 24
+#define TRAV_SPILL_STACK 72
+#define TRAV_BLOCK 256
+
+struct DevSphere {
+    float trans[16];
+    float itrans[16];
+};
+
+// Hit encoding in the per-path hit buffer: `ref`
+//   >= 0 : triangle slot (index into tri_q / tri_mat / tri_prim)
+//   -1   : miss
+//   <= -2: sphere slot s = -(ref + 2)
+#define HIT_MISS (-1)
+#define HIT_SPHERE(s) (-(int)(s)-2)
+#define HIT_SPHERE_SLOT(ref) (-(ref)-2)
+
+#define MAT_LIGHT_BIT 0x80000000u
+
+struct DevScene {
+    // geometry (BVH leaf order)
+    const float4* tri_q;        // 3 per triangle slot
+    const uint32_t* tri_mat;    // material id | MAT_LIGHT_BIT
+    const int32_t* tri_prim;    // slot -> global primitive index
+    const DevSphere* spheres;   // sphere slot order
+    const uint32_t* sph_mat;
+    const int32_t* sph_prim;    // slot -> global primitive index (T + sphere index)
+    const PtcMaterialValue* materials;
+    const BvhNode* nodes;       // nodes[0] = root
+    uint32_t n_tris, n_spheres, n_nodes;
+    // lights
+    const PtcPointLight* plights;
+    const PtcDirectionalLight* dlights;
+    const PtcQuadLight* qlights;
+    uint32_t n_plights, n_dlights, n_qlights;
+};
+
+enum { INT_RAYTRACER = 0, INT_ANALYTICDIRECT = 1, INT_DIRECT = 2, INT_PATHTRACER = 3, INT_PATHTRACER2 = 4 };
+
+struct RenderParams {
+    PtcConfig cf;
+    uint32_t light_samples, light_stratify, sampling_method;
+    int32_t integrator;
+    float bg[3];
+    uint32_t width, height;
+    uint32_t frame_id;
+    uint32_t max_depth_eff;   // min(cf.maxDepth, bounce cap)
+    uint32_t bounce_cap;
+    int32_t semantics;        // 0 literal, 1 intended
+    int32_t seeding;          // 0 reference, 1 counter
+    int32_t cull_zero;
+    int32_t brute_force;
+    uint32_t samples_per_path;  // shadow-ray samples per segment (integrator dependent)
+    uint32_t root_light_samples;
+};
+
+// Per-path state, structure of arrays, `capacity` entries each.
+struct PathState {
+    float4* o_seed;    // origin.xyz, seed of the coming segment (bits)
+    float4* d_depth;   // direction.xyz, depth (bits)
+    float4* thr;       // throughput.xyz, segment number within the path (bits)
+    float4* L;         // radiance accumulated by this path
+    float* hit_t;      // closest-hit distance of the current segment
+    int32_t* hit_ref;  // see HIT_*
+    float* contrib;    // [sample][capacity][3 planes]: per-shadow-sample f*G terms
+    uint32_t capacity;
+};

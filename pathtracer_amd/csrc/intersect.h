@@ -1,0 +1,298 @@
+// intersect.h -- primitive tests and BVH traversal (device code).
+//
+// The primitive tests restate the reference's intersection programs operation
+// by operation (Triangle.cu:12-60, Sphere.cu:13-58) so that t/u/v are bit-equal
+// to a plain IEEE evaluation of that source; the BVH only decides WHICH
+// primitives get tested.  Acceptance follows rtPotentialIntersection:
+// tmin < t < current tmax; equal distances are resolved towards the lowest
+// global primitive index, which makes the closest hit independent of
+// traversal order.
+#pragma once
+
+#include "device_scene.h"
+
+struct Cand {
+    bool hit;
+    float t, u, v;
+};
+
+// Triangle.cu:15-46.  q0=(v1,n.x) q1=(v2,n.y) q2=(v3,n.z).
+__device__ __forceinline__ Cand tri_candidate(float4 q0, float4 q1, float4 q2, vec3 o, vec3 d) {
+    Cand c;
+    c.hit = false;
+    c.t = c.u = c.v = 0.f;
+    vec3 n = mk3(q0.w, q1.w, q2.w);
+    vec3 v1 = mk3(q0.x, q0.y, q0.z), v2 = mk3(q1.x, q1.y, q1.z), v3 = mk3(q2.x, q2.y, q2.z);
+    if (dot(d, n) >= .0f) n = -n;
+    float nDotWo = dot(n, -d);
+    if (nDotWo == 0.0f) return c;
+    float t = dot(v1 - o, n) / dot(d, n);
+    vec3 P = o + t * d;
+    // `t < 0.001` is a double comparison in the source; 0.001f is the smallest
+    // float above the double 0.001, so the float comparison is equivalent.
+    if (t < 0.001f) return c;
+    vec3 tmp0 = v3 - v1, tmp1 = v2 - v1, tmp2 = P - v1;
+    float d00 = dot(tmp0, tmp0), d01 = dot(tmp0, tmp1), d02 = dot(tmp0, tmp2);
+    float d11 = dot(tmp1, tmp1), d12 = dot(tmp1, tmp2);
+    float denom = d00 * d11 - d01 * d01;
+    float u = (d11 * d02 - d01 * d12) / denom;
+    float v = (d00 * d12 - d01 * d02) / denom;
+    if (0 > u || u > 1 || 0 > v || v > 1 || u + v > 1) return c;
+    c.hit = true;
+    c.t = t;
+    c.u = u;
+    c.v = v;
+    return c;
+}
+
+// Sphere.cu:16-42 with the inverse transform precomputed at upload (same
+// cofactor routine, so the same bits).  `epsilon` of Sphere.cu:9 is never set
+// by the reference host; it is taken as 0.  Pw receives the world-space point.
+__device__ __forceinline__ Cand sphere_candidate(const DevSphere& sp, vec3 o, vec3 d, vec3* Pw) {
+    Cand c;
+    c.hit = false;
+    c.t = c.u = c.v = 0.f;
+    const float* it = sp.itrans;
+    const float* tr = sp.trans;
+    float ohx = it[0] * o.x + it[1] * o.y + it[2] * o.z + it[3] * 1.f;
+    float ohy = it[4] * o.x + it[5] * o.y + it[6] * o.z + it[7] * 1.f;
+    float ohz = it[8] * o.x + it[9] * o.y + it[10] * o.z + it[11] * 1.f;
+    float ohw = it[12] * o.x + it[13] * o.y + it[14] * o.z + it[15] * 1.f;
+    vec3 rayOri = mk3(ohx, ohy, ohz) / ohw;
+    float dhx = it[0] * d.x + it[1] * d.y + it[2] * d.z + it[3] * 0.f;
+    float dhy = it[4] * d.x + it[5] * d.y + it[6] * d.z + it[7] * 0.f;
+    float dhz = it[8] * d.x + it[9] * d.y + it[10] * d.z + it[11] * 0.f;
+    vec3 rayDir = normalize(mk3(dhx, dhy, dhz));
+    float t = 0;
+    float b = dot(rayDir, rayOri);
+    float cc = dot(rayOri, rayOri);
+    float r2 = 1.f;
+    float disc = b * b - cc + r2;
+    if (disc < 0) return c;
+    if (disc == 0)
+        t = -b;
+    else if (cc > r2)
+        t = -b - sqrtf(disc);
+    else
+        t = -b + sqrtf(disc);
+    if (t < 0.0f) return c;
+    vec3 P = rayOri + t * rayDir;
+    float ihx = tr[0] * P.x + tr[1] * P.y + tr[2] * P.z + tr[3] * 1.f;
+    float ihy = tr[4] * P.x + tr[5] * P.y + tr[6] * P.z + tr[7] * 1.f;
+    float ihz = tr[8] * P.x + tr[9] * P.y + tr[10] * P.z + tr[11] * 1.f;
+    float ihw = tr[12] * P.x + tr[13] * P.y + tr[14] * P.z + tr[15] * 1.f;
+    P = mk3(ihx, ihy, ihz) / ihw;
+    t = length(P - o);
+    c.hit = true;
+    c.t = t;
+    if (Pw) *Pw = P;
+    return c;
+}
+
+// Attributes of an accepted hit (Geometries.h:40-45).
+struct HitAttr {
+    vec3 P, normal, wo;
+    uint32_t mat;  // material id | MAT_LIGHT_BIT
+};
+
+__device__ __forceinline__ void hit_attributes(const DevScene& sc, int ref, float t, vec3 o, vec3 d, HitAttr& a) {
+    if (ref >= 0) {  // Triangle.cu:48-58
+        const float4* q = sc.tri_q + 3 * (size_t)ref;
+        float4 q0 = q[0], q1 = q[1], q2 = q[2];
+        vec3 n = mk3(q0.w, q1.w, q2.w);
+        if (dot(d, n) >= .0f) n = -n;
+        float nDotWo = dot(n, -d);
+        a.P = o + t * d;
+        a.wo = -d;
+        a.normal = nDotWo > 0 ? n : -n;
+        a.mat = sc.tri_mat[ref];
+    } else {  // Sphere.cu:45-56
+        int s = HIT_SPHERE_SLOT(ref);
+        const DevSphere& sp = sc.spheres[s];
+        vec3 P;
+        sphere_candidate(sp, o, d, &P);
+        const float* it = sp.itrans;
+        a.P = P;
+        a.wo = -d;
+        float tx = it[0] * P.x + it[1] * P.y + it[2] * P.z + it[3] * 1.f;
+        float ty = it[4] * P.x + it[5] * P.y + it[6] * P.z + it[7] * 1.f;
+        float tz = it[8] * P.x + it[9] * P.y + it[10] * P.z + it[11] * 1.f;
+        float tw = it[12] * P.x + it[13] * P.y + it[14] * P.z + it[15] * 1.f;
+        vec3 nobj = normalize(mk3(tx, ty, tz) / tw);
+        // (inverse)^T * (n,0): column sums of the inverse
+        float nx = it[0] * nobj.x + it[4] * nobj.y + it[8] * nobj.z + it[12] * 0.f;
+        float ny = it[1] * nobj.x + it[5] * nobj.y + it[9] * nobj.z + it[13] * 0.f;
+        float nz = it[2] * nobj.x + it[6] * nobj.y + it[10] * nobj.z + it[14] * 0.f;
+        a.normal = normalize(mk3(nx, ny, nz));
+        a.mat = sc.sph_mat[s];  // spheres always report objType OBJECT (Sphere.cu:55)
+    }
+}
+
+// ------------------------------------------------------------- traversal --
+
+struct TravCounters {
+    uint32_t nodes, prims;
+};
+
+struct ClosestHit {
+    float t;
+    int ref;       // HIT_* encoding
+    int prim;      // global primitive index of the current best, -1 when not loaded yet
+};
+
+__device__ __forceinline__ void accept_tri(const DevScene& sc, uint32_t slot, vec3 o, vec3 d, float tmin, float tmax, ClosestHit& best) {
+    const float4* q = sc.tri_q + 3 * (size_t)slot;
+    Cand c = tri_candidate(q[0], q[1], q[2], o, d);
+    if (!c.hit || !(c.t > tmin && c.t < tmax)) return;
+    if (best.ref != HIT_MISS && !(c.t < best.t)) {
+        if (c.t != best.t) return;
+        // exact tie: lowest global primitive index wins
+        if (best.prim < 0) best.prim = best.ref >= 0 ? sc.tri_prim[best.ref] : sc.sph_prim[HIT_SPHERE_SLOT(best.ref)];
+        int prim = sc.tri_prim[slot];
+        if (prim > best.prim) return;
+        best.prim = prim;
+    } else {
+        best.prim = -1;
+    }
+    best.t = c.t;
+    best.ref = (int)slot;
+}
+
+__device__ __forceinline__ void accept_sphere(const DevScene& sc, uint32_t slot, vec3 o, vec3 d, float tmin, float tmax, ClosestHit& best) {
+    Cand c = sphere_candidate(sc.spheres[slot], o, d, nullptr);
+    if (!c.hit || !(c.t > tmin && c.t < tmax)) return;
+    if (best.ref != HIT_MISS && !(c.t < best.t)) {
+        if (c.t != best.t) return;
+        if (best.prim < 0) best.prim = best.ref >= 0 ? sc.tri_prim[best.ref] : sc.sph_prim[HIT_SPHERE_SLOT(best.ref)];
+        int prim = sc.sph_prim[slot];
+        if (prim > best.prim) return;
+        best.prim = prim;
+    } else {
+        best.prim = -1;
+    }
+    best.t = c.t;
+    best.ref = HIT_SPHERE(slot);
+}
+
+__device__ __forceinline__ bool any_tri(const DevScene& sc, uint32_t slot, vec3 o, vec3 d, float tmin, float tmax) {
+    const float4* q = sc.tri_q + 3 * (size_t)slot;
+    Cand c = tri_candidate(q[0], q[1], q[2], o, d);
+    return c.hit && c.t > tmin && c.t < tmax;
+}
+__device__ __forceinline__ bool any_sphere(const DevScene& sc, uint32_t slot, vec3 o, vec3 d, float tmin, float tmax) {
+    Cand c = sphere_candidate(sc.spheres[slot], o, d, nullptr);
+    return c.hit && c.t > tmin && c.t < tmax;
+}
+
+__device__ __forceinline__ bool dir_is_nan(vec3 d) { return (d.x != d.x) || (d.y != d.y) || (d.z != d.z); }
+
+// One traversal routine for both ray types.
+//   ANY = false: closest hit into `best` (rtTrace, ray type 0)
+//   ANY = true : returns true as soon as one primitive is accepted (ray type 1,
+//                the any-hit program of Common.cu:30-36 terminates the ray)
+// `lds_stack` points at this thread's column of a [TRAV_LDS_STACK][TRAV_BLOCK]
+// LDS array (entry i at lds_stack[i*TRAV_BLOCK]).
+// A ray whose direction has a NaN component can never be accepted by either
+// primitive test (every comparison on t fails), so it is a miss up front.
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ bool traverse(const DevScene& sc, vec3 o, vec3 d, float tmin, float tmax, uint32_t* lds_stack, ClosestHit& best, TravCounters& cnt) {
+    best.t = tmax;
+    best.ref = HIT_MISS;
+    best.prim = -1;
+    if (dir_is_nan(d) || sc.n_nodes == 0) return false;
+    const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+    uint32_t spill[TRAV_SPILL_STACK];
+    int sp = 0;
+    uint32_t cur = 0;  // internal node 0 = root
+    for (;;) {
+        const uint32_t kind = REF_KIND(cur);
+        if (kind == REF_INTERNAL) {
+            const float4* n4 = reinterpret_cast<const float4*>(sc.nodes + REF_NODE(cur));
+            const float4 a = n4[0], b = n4[1], c = n4[2];
+            const uint4 ch = *reinterpret_cast<const uint4*>(n4 + 3);
+            if (COUNT) cnt.nodes++;
+            const float lim = ANY ? tmax : best.t;
+            // child 0: lo=(a.x,a.y,a.z) hi=(a.w,b.x,b.y)
+            float t0 = (a.x - o.x) * ix, t1 = (a.w - o.x) * ix;
+            float n0 = fminf(t0, t1), f0 = fmaxf(t0, t1);
+            t0 = (a.y - o.y) * iy; t1 = (b.x - o.y) * iy;
+            n0 = fmaxf(n0, fminf(t0, t1)); f0 = fminf(f0, fmaxf(t0, t1));
+            t0 = (a.z - o.z) * iz; t1 = (b.y - o.z) * iz;
+            n0 = fmaxf(n0, fminf(t0, t1)); f0 = fminf(f0, fmaxf(t0, t1));
+            n0 = fmaxf(n0, tmin); f0 = fminf(f0, lim);
+            // child 1: lo=(b.z,b.w,c.x) hi=(c.y,c.z,c.w)
+            t0 = (b.z - o.x) * ix; t1 = (c.y - o.x) * ix;
+            float n1 = fminf(t0, t1), f1 = fmaxf(t0, t1);
+            t0 = (b.w - o.y) * iy; t1 = (c.z - o.y) * iy;
+            n1 = fmaxf(n1, fminf(t0, t1)); f1 = fminf(f1, fmaxf(t0, t1));
+            t0 = (c.x - o.z) * iz; t1 = (c.w - o.z) * iz;
+            n1 = fmaxf(n1, fminf(t0, t1)); f1 = fminf(f1, fmaxf(t0, t1));
+            n1 = fmaxf(n1, tmin); f1 = fminf(f1, lim);
+            const bool h0 = (n0 <= f0) && (REF_KIND(ch.x) != REF_EMPTY);
+            const bool h1 = (n1 <= f1) && (REF_KIND(ch.y) != REF_EMPTY);
+            if (h0 && h1) {
+                const bool swap = n1 < n0;
+                const uint32_t nearc = swap ? ch.y : ch.x, farc = swap ? ch.x : ch.y;
+                if (sp < TRAV_LDS_STACK) lds_stack[sp * TRAV_BLOCK] = farc;
+                else spill[sp - TRAV_LDS_STACK] = farc;
+                ++sp;
+                cur = nearc;
+                continue;
+            } else if (h0) {
+                cur = ch.x;
+                continue;
+            } else if (h1) {
+                cur = ch.y;
+                continue;
+            }
+        } else if (kind == REF_TRI) {
+            const uint32_t first = REF_FIRST(cur), count = REF_COUNT(cur);
+            for (uint32_t k = 0; k < count; ++k) {
+                if (COUNT) cnt.prims++;
+                if (ANY) {
+                    if (any_tri(sc, first + k, o, d, tmin, tmax)) return true;
+                } else {
+                    accept_tri(sc, first + k, o, d, tmin, tmax, best);
+                }
+            }
+        } else if (kind == REF_SPHERE) {
+            const uint32_t first = REF_FIRST(cur), count = REF_COUNT(cur);
+            for (uint32_t k = 0; k < count; ++k) {
+                if (COUNT) cnt.prims++;
+                if (ANY) {
+                    if (any_sphere(sc, first + k, o, d, tmin, tmax)) return true;
+                } else {
+                    accept_sphere(sc, first + k, o, d, tmin, tmax, best);
+                }
+            }
+        }
+        if (sp == 0) break;
+        --sp;
+        cur = sp < TRAV_LDS_STACK ? lds_stack[sp * TRAV_BLOCK] : spill[sp - TRAV_LDS_STACK];
+    }
+    return false;
+}
+
+// Brute force over every primitive (parity aid; also the reference point the BVH
+// path is compared with).
+template <bool ANY>
+__device__ __forceinline__ bool brute_force(const DevScene& sc, vec3 o, vec3 d, float tmin, float tmax, ClosestHit& best) {
+    best.t = tmax;
+    best.ref = HIT_MISS;
+    best.prim = -1;
+    for (uint32_t s = 0; s < sc.n_tris; ++s) {
+        if (ANY) {
+            if (any_tri(sc, s, o, d, tmin, tmax)) return true;
+        } else {
+            accept_tri(sc, s, o, d, tmin, tmax, best);
+        }
+    }
+    for (uint32_t s = 0; s < sc.n_spheres; ++s) {
+        if (ANY) {
+            if (any_sphere(sc, s, o, d, tmin, tmax)) return true;
+        } else {
+            accept_sphere(sc, s, o, d, tmin, tmax, best);
+        }
+    }
+    return false;
+}

@@ -1,0 +1,729 @@
+// ptcore.hip -- the C ABI of include/ptcore.h: context, uploads, wavefront
+// scheduling of the kernels in wavefront.hip and the BVH build of bvh_build.hip.
+//
+// The control flow of one render is the reference's Renderer::run ->
+// context->launch (Renderer.cpp:27-37) unrolled into batches: a batch holds
+// `n` samples of every pixel; its paths are generated, then extended /
+// connected / shaded bounce by bounce while the queue of live paths shrinks,
+// and finally summed into the per-pixel radiance sums in sample order.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "ptcore.h"
+#include "wavefront.h"
+
+namespace {
+std::string g_create_error;
+const char* kIntegrators[] = {"raytracer", "analyticdirect", "direct", "pathtracer", "pathtracer2"};
+}  // namespace
+
+struct ptc_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    std::string error;
+
+    // scene (host copies of what was uploaded)
+    PtcConfig cfg{};
+    bool have_cfg = false;
+    int integrator = -1;
+    uint32_t light_samples = 1, light_stratify = 0, next_event_est = 0, sampling_method = 0;
+    int32_t spp = 1;
+    float bg[3] = {0.f, 0.f, 0.f};
+    std::vector<PtcTriangle> tris;
+    std::vector<PtcSphere> spheres;
+    std::vector<PtcPointLight> plights;
+    std::vector<PtcDirectionalLight> dlights;
+    std::vector<PtcQuadLight> qlights;
+    bool non_diffuse = false;
+
+    // device scene
+    PtcTriangle* d_tris = nullptr;
+    PtcSphere* d_spheres = nullptr;
+    PtcMaterialValue* d_materials = nullptr;
+    PtcPointLight* d_plights = nullptr;
+    PtcDirectionalLight* d_dlights = nullptr;
+    PtcQuadLight* d_qlights = nullptr;
+    BvhBuildOutput bvh;
+    bool built = false;
+    bool lights_dirty = true;
+
+    // render targets
+    uint32_t width = 0, height = 0, npix_pad = 0;
+    float* acc_own = nullptr;
+    float* acc = nullptr;  // acc_own or the caller's buffer
+    void* acc_ext = nullptr;
+    size_t acc_ext_bytes = 0;
+    float* result = nullptr;
+    uint32_t* segctr = nullptr;
+    int32_t ref_next_sample = 0;  // reference seeding: the sample the per-pixel history is at
+    PtcHitRecord* d_hits = nullptr;
+
+    // wavefront state
+    PathState ps{};
+    uint32_t contrib_samples = 0;
+    uint32_t* queue[2] = {nullptr, nullptr};
+    uint32_t* qcount = nullptr;                 // [2]
+    unsigned long long* counters = nullptr;     // [0..3] traversal, [4] shadow rays
+    uint32_t* h_count = nullptr;                // pinned
+
+    // options
+    int semantics = 0, seeding = 0, cull_zero = 1, profile = 0, count_trav = 0, brute_force = 0;
+    uint32_t bounce_cap = 1024;
+    uint64_t batch_paths = 8u << 20;
+
+    PtcStats stats{};
+    std::vector<hipEvent_t> ev_pool;
+    struct Span { int kind; hipEvent_t a, b; };
+    std::vector<Span> spans;
+    size_t ev_used = 0;
+};
+
+namespace {
+
+int fail(ptc_context* c, int code, const std::string& msg) {
+    if (c) c->error = msg;
+    return code;
+}
+
+#define CHK(call)                                                                                   \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess) return fail(ctx, PTC_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+template <class T>
+hipError_t upload(T*& dst, const std::vector<T>& src, hipStream_t s) {
+    if (dst) {
+        (void)hipFree(dst);
+        dst = nullptr;
+    }
+    hipError_t e = hipMalloc((void**)&dst, std::max<size_t>(src.size(), 1) * sizeof(T));
+    if (e != hipSuccess) return e;
+    if (!src.empty()) e = hipMemcpyAsync(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(s);
+}
+
+void freeTargets(ptc_context* c) {
+    for (void* p : {(void*)c->acc_own, (void*)c->result, (void*)c->segctr, (void*)c->d_hits})
+        if (p) (void)hipFree(p);
+    c->acc_own = c->result = nullptr;
+    c->segctr = nullptr;
+    c->d_hits = nullptr;
+    c->width = c->height = c->npix_pad = 0;
+}
+
+void freePaths(ptc_context* c) {
+    for (void* p : {(void*)c->ps.o_seed, (void*)c->ps.d_depth, (void*)c->ps.thr, (void*)c->ps.L, (void*)c->ps.hit_t, (void*)c->ps.hit_ref,
+                    (void*)c->ps.contrib, (void*)c->queue[0], (void*)c->queue[1]})
+        if (p) (void)hipFree(p);
+    c->ps = PathState{};
+    c->queue[0] = c->queue[1] = nullptr;
+    c->contrib_samples = 0;
+}
+
+int ensureTargets(ptc_context* ctx, uint32_t w, uint32_t h) {
+    if (w == 0 || h == 0) return fail(ctx, PTC_ERR_INVALID, "image size must be non-zero");
+    if (ctx->width == w && ctx->height == h) {
+        ctx->acc = ctx->acc_ext ? (float*)ctx->acc_ext : ctx->acc_own;
+        return PTC_OK;
+    }
+    freeTargets(ctx);
+    const size_t n = (size_t)w * h;
+    const uint32_t tiles = ((w + 7u) / 8u) * ((h + 7u) / 8u);
+    CHK(hipMalloc((void**)&ctx->acc_own, n * 3 * sizeof(float)));
+    CHK(hipMalloc((void**)&ctx->result, n * 3 * sizeof(float)));
+    CHK(hipMalloc((void**)&ctx->segctr, (size_t)tiles * 64 * sizeof(uint32_t)));
+    CHK(hipMalloc((void**)&ctx->d_hits, n * sizeof(PtcHitRecord)));
+    CHK(hipMemsetAsync(ctx->acc_own, 0, n * 3 * sizeof(float), ctx->stream));
+    CHK(hipMemsetAsync(ctx->result, 0, n * 3 * sizeof(float), ctx->stream));
+    CHK(hipMemsetAsync(ctx->segctr, 0, (size_t)tiles * 64 * sizeof(uint32_t), ctx->stream));
+    ctx->width = w;
+    ctx->height = h;
+    ctx->npix_pad = tiles * 64u;
+    ctx->ref_next_sample = 0;
+    ctx->acc = ctx->acc_ext ? (float*)ctx->acc_ext : ctx->acc_own;
+    return PTC_OK;
+}
+
+int ensurePaths(ptc_context* ctx, uint32_t capacity, uint32_t contrib_samples) {
+    if (ctx->ps.capacity >= capacity && ctx->contrib_samples >= contrib_samples) return PTC_OK;
+    capacity = std::max(capacity, ctx->ps.capacity);
+    contrib_samples = std::max(contrib_samples, ctx->contrib_samples);
+    freePaths(ctx);
+    CHK(hipMalloc((void**)&ctx->ps.o_seed, (size_t)capacity * sizeof(float4)));
+    CHK(hipMalloc((void**)&ctx->ps.d_depth, (size_t)capacity * sizeof(float4)));
+    CHK(hipMalloc((void**)&ctx->ps.thr, (size_t)capacity * sizeof(float4)));
+    CHK(hipMalloc((void**)&ctx->ps.L, (size_t)capacity * sizeof(float4)));
+    CHK(hipMalloc((void**)&ctx->ps.hit_t, (size_t)capacity * sizeof(float)));
+    CHK(hipMalloc((void**)&ctx->ps.hit_ref, (size_t)capacity * sizeof(int32_t)));
+    CHK(hipMalloc((void**)&ctx->ps.contrib, std::max<size_t>((size_t)capacity * contrib_samples * 3, 1) * sizeof(float)));
+    CHK(hipMalloc((void**)&ctx->queue[0], (size_t)capacity * sizeof(uint32_t)));
+    CHK(hipMalloc((void**)&ctx->queue[1], (size_t)capacity * sizeof(uint32_t)));
+    ctx->ps.capacity = capacity;
+    ctx->contrib_samples = contrib_samples;
+    return PTC_OK;
+}
+
+uint32_t samplesPerSegment(const ptc_context* c, uint32_t root) {
+    switch (c->integrator) {
+        case INT_RAYTRACER: return (uint32_t)(c->plights.size() + c->dlights.size());
+        case INT_ANALYTICDIRECT: return 0;
+        case INT_DIRECT: return (uint32_t)c->qlights.size() * root * root;
+        case INT_PATHTRACER: return c->cfg.next_event_est ? (uint32_t)c->qlights.size() * root * root : 0u;
+        case INT_PATHTRACER2: return (uint32_t)c->qlights.size() * root * root;
+    }
+    return 0;
+}
+
+hipEvent_t takeEvent(ptc_context* c) {
+    if (c->ev_used == c->ev_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        c->ev_pool.push_back(e);
+    }
+    return c->ev_pool[c->ev_used++];
+}
+
+struct Timed {  // brackets a launch with events when profiling is on
+    ptc_context* c;
+    int kind;
+    hipEvent_t a = nullptr, b = nullptr;
+    Timed(ptc_context* c_, int kind_) : c(c_), kind(kind_) {
+        if (c->profile) {
+            a = takeEvent(c);
+            b = takeEvent(c);
+            if (a) (void)hipEventRecord(a, c->stream);
+        }
+    }
+    ~Timed() {
+        if (a && b) {
+            (void)hipEventRecord(b, c->stream);
+            c->spans.push_back({kind, a, b});
+        }
+    }
+};
+
+void collectSpans(ptc_context* c) {  // stream must be idle
+    for (auto& sp : c->spans) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
+            double* dst = sp.kind == 0 ? &c->stats.extend_ms : sp.kind == 1 ? &c->stats.connect_ms : sp.kind == 2 ? &c->stats.shade_ms : &c->stats.other_ms;
+            *dst += ms;
+        }
+    }
+    c->spans.clear();
+    c->ev_used = 0;
+}
+
+DevScene deviceScene(const ptc_context* c) {
+    DevScene sc{};
+    sc.tri_q = c->bvh.tri_q;
+    sc.tri_mat = c->bvh.tri_mat;
+    sc.tri_prim = c->bvh.tri_prim;
+    sc.spheres = c->bvh.spheres;
+    sc.sph_mat = c->bvh.sph_mat;
+    sc.sph_prim = c->bvh.sph_prim;
+    sc.materials = c->d_materials;
+    sc.nodes = c->bvh.nodes;
+    sc.n_tris = (uint32_t)c->tris.size();
+    sc.n_spheres = (uint32_t)c->spheres.size();
+    sc.n_nodes = c->bvh.n_nodes;
+    sc.plights = c->d_plights;
+    sc.dlights = c->d_dlights;
+    sc.qlights = c->d_qlights;
+    sc.n_plights = (uint32_t)c->plights.size();
+    sc.n_dlights = (uint32_t)c->dlights.size();
+    sc.n_qlights = (uint32_t)c->qlights.size();
+    return sc;
+}
+
+int makeParams(ptc_context* ctx, int frame_id, uint32_t w, uint32_t h, RenderParams& rp) {
+    if (!ctx->have_cfg) return fail(ctx, PTC_ERR_INVALID, "ptc_set_config has not been called");
+    if (ctx->integrator < 0) return fail(ctx, PTC_ERR_INVALID, "ptc_set_integrator has not been called");
+    if (!ctx->built) return fail(ctx, PTC_ERR_NOT_BUILT, "ptc_build has not been called since the last geometry upload");
+    if (ctx->integrator == INT_PATHTRACER && ctx->non_diffuse)
+        return fail(ctx, PTC_ERR_UNSUPPORTED, "glass / volumetric materials are outside the built path (pathtracer integrator)");
+    std::memset(&rp, 0, sizeof(rp));
+    rp.cf = ctx->cfg;
+    rp.cf.next_event_est = ctx->next_event_est;
+    rp.light_samples = ctx->light_samples;
+    rp.light_stratify = ctx->light_stratify;
+    rp.sampling_method = ctx->sampling_method;
+    rp.integrator = ctx->integrator;
+    std::memcpy(rp.bg, ctx->bg, sizeof(rp.bg));
+    rp.width = w;
+    rp.height = h;
+    rp.frame_id = (uint32_t)frame_id;
+    rp.bounce_cap = ctx->bounce_cap;
+    rp.max_depth_eff = std::min<uint32_t>(ctx->cfg.maxDepth, ctx->bounce_cap);
+    rp.semantics = ctx->semantics;
+    rp.seeding = ctx->seeding;
+    rp.cull_zero = ctx->cull_zero;
+    rp.brute_force = ctx->brute_force;
+    rp.root_light_samples = (uint32_t)(int)sqrtf((float)ctx->light_samples);
+    rp.samples_per_path = samplesPerSegment(ctx, rp.root_light_samples);
+    return PTC_OK;
+}
+
+int uploadLights(ptc_context* ctx) {
+    if (!ctx->lights_dirty) return PTC_OK;
+    CHK(upload(ctx->d_plights, ctx->plights, ctx->stream));
+    CHK(upload(ctx->d_dlights, ctx->dlights, ctx->stream));
+    CHK(upload(ctx->d_qlights, ctx->qlights, ctx->stream));
+    ctx->lights_dirty = false;
+    return PTC_OK;
+}
+
+// Trace every bounce of the paths in queue[0] (count0 of them).
+int runBounces(ptc_context* ctx, const RenderParams& rp, const DevScene& sc, uint32_t count0, uint32_t sample_begin) {
+    uint32_t count = count0;
+    int cur = 0;
+    const uint32_t S = rp.samples_per_path;
+    while (count > 0) {
+        {
+            Timed t(ctx, 0);
+            wf_extend(ctx->stream, rp, sc, ctx->ps, ctx->queue[cur], count, ctx->count_trav != 0, ctx->counters);
+        }
+        ctx->stats.extension_rays += count;
+        ctx->stats.extend_launches++;
+        if (S) {
+            Timed t(ctx, 1);
+            wf_connect(ctx->stream, rp, sc, ctx->ps, ctx->queue[cur], count, S, ctx->count_trav != 0, ctx->counters, ctx->counters + 4);
+            ctx->stats.connect_launches++;
+        }
+        CHK(hipMemsetAsync(ctx->qcount + (cur ^ 1), 0, sizeof(uint32_t), ctx->stream));
+        {
+            Timed t(ctx, 2);
+            wf_shade(ctx->stream, rp, sc, ctx->ps, ctx->queue[cur], count, ctx->npix_pad, sample_begin, ctx->segctr, ctx->queue[cur ^ 1], ctx->qcount + (cur ^ 1));
+        }
+        ctx->stats.shade_launches++;
+        CHK(hipMemcpyAsync(ctx->h_count, ctx->qcount + (cur ^ 1), sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        CHK(hipStreamSynchronize(ctx->stream));
+        CHK(hipGetLastError());
+        count = *ctx->h_count;
+        cur ^= 1;
+    }
+    return PTC_OK;
+}
+
+int renderRange(ptc_context* ctx, int frame_id, uint32_t w, uint32_t h, int32_t j0, int32_t j1, int clear) {
+    RenderParams rp;
+    int rc = makeParams(ctx, frame_id, w, h, rp);
+    if (rc) return rc;
+    if (j0 < 0 || j1 < j0) return fail(ctx, PTC_ERR_INVALID, "bad sample range");
+    if ((uint32_t)j1 > (1u << 20)) return fail(ctx, PTC_ERR_INVALID, "at most 2^20 samples per pixel");
+    rc = ensureTargets(ctx, w, h);
+    if (rc) return rc;
+    rc = uploadLights(ctx);
+    if (rc) return rc;
+    const size_t npix = (size_t)w * h;
+    if (clear) {
+        CHK(hipMemsetAsync(ctx->acc, 0, npix * 3 * sizeof(float), ctx->stream));
+        if (j0 == 0) {
+            CHK(hipMemsetAsync(ctx->segctr, 0, (size_t)ctx->npix_pad * sizeof(uint32_t), ctx->stream));
+            ctx->ref_next_sample = 0;
+        }
+    }
+    if (rp.seeding == 0 && j1 > j0 && j0 != ctx->ref_next_sample)
+        return fail(ctx, PTC_ERR_INVALID, "reference seeding depends on the pixel's earlier samples: ranges must start at 0 (with clear) or continue the previous range");
+    const DevScene sc = deviceScene(ctx);
+    const uint32_t S = rp.samples_per_path;
+    // samples of every pixel per batch
+    uint64_t per_batch = rp.seeding == 0 ? 1u : std::max<uint64_t>(1u, ctx->batch_paths / ctx->npix_pad);
+    if (S) per_batch = std::max<uint64_t>(1u, std::min<uint64_t>(per_batch, (6ull << 30) / ((uint64_t)ctx->npix_pad * S * 12ull)));
+    per_batch = std::min<uint64_t>(per_batch, (uint64_t)std::max(1, j1 - j0));
+    if ((uint64_t)ctx->npix_pad * per_batch > 0xFFFFFFF0ull) return fail(ctx, PTC_ERR_INVALID, "batch too large");
+    rc = ensurePaths(ctx, (uint32_t)(ctx->npix_pad * per_batch), S);
+    if (rc) return rc;
+    for (int32_t ja = j0; ja < j1; ja += (int32_t)per_batch) {
+        const uint32_t ns = (uint32_t)std::min<int64_t>((int64_t)per_batch, j1 - ja);
+        const uint32_t n_paths = ns * ctx->npix_pad;
+        const int seedL = rp.seeding == 0 ? 1 : 0;  // reference order: result += radiance per segment
+        CHK(hipMemsetAsync(ctx->qcount, 0, 2 * sizeof(uint32_t), ctx->stream));
+        {
+            Timed t(ctx, 3);
+            wf_generate(ctx->stream, rp, ctx->ps, ctx->npix_pad, n_paths, (uint32_t)ja, ctx->acc, ctx->segctr, seedL, ctx->queue[0], ctx->qcount);
+        }
+        CHK(hipMemcpyAsync(ctx->h_count, ctx->qcount, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        CHK(hipStreamSynchronize(ctx->stream));
+        const uint32_t count0 = *ctx->h_count;
+        ctx->stats.paths += count0;
+        rc = runBounces(ctx, rp, sc, count0, (uint32_t)ja);
+        if (rc) return rc;
+        {
+            Timed t(ctx, 3);
+            wf_accumulate(ctx->stream, rp, ctx->ps, ctx->npix_pad, ns, ctx->acc, seedL);
+        }
+        if (ctx->profile) {
+            CHK(hipStreamSynchronize(ctx->stream));
+            collectSpans(ctx);
+        }
+    }
+    if (rp.seeding == 0) ctx->ref_next_sample = j1;
+    CHK(hipGetLastError());
+    return PTC_OK;
+}
+
+int enter(ptc_context* ctx) {
+    if (!ctx) return PTC_ERR_INVALID;
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return fail(ctx, PTC_ERR_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    return PTC_OK;
+}
+#define ENTER()                  \
+    do {                         \
+        int rc_ = enter(ctx);    \
+        if (rc_) return rc_;     \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int ptc_create(int device_ordinal, ptc_context** out) {
+    if (!out) {
+        g_create_error = "ptc_create: null output pointer";
+        return PTC_ERR_INVALID;
+    }
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) {
+        g_create_error = std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+        return PTC_ERR_DEVICE;
+    }
+    if (device_ordinal < 0 || device_ordinal >= n) {
+        g_create_error = "ptc_create: device ordinal out of range";
+        return PTC_ERR_INVALID;
+    }
+    e = hipSetDevice(device_ordinal);
+    if (e != hipSuccess) {
+        g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e);
+        return PTC_ERR_DEVICE;
+    }
+    ptc_context* ctx = new ptc_context;
+    ctx->device = device_ordinal;
+    auto bail = [&](const char* what, hipError_t err) {
+        g_create_error = std::string(what) + ": " + hipGetErrorString(err);
+        delete ctx;
+        return PTC_ERR_DEVICE;
+    };
+    if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    ctx->stream = ctx->own_stream;
+    if ((e = hipMalloc((void**)&ctx->qcount, 2 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc((void**)&ctx->counters, 8 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMemset(ctx->counters, 0, 8 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
+    if ((e = hipHostMalloc((void**)&ctx->h_count, sizeof(uint32_t))) != hipSuccess) return bail("hipHostMalloc", e);
+    *out = ctx;
+    return PTC_OK;
+}
+
+int ptc_destroy(ptc_context* ctx) {
+    if (!ctx) return PTC_ERR_INVALID;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    freeTargets(ctx);
+    freePaths(ctx);
+    bvh_free(ctx->bvh);
+    for (void* p : {(void*)ctx->d_tris, (void*)ctx->d_spheres, (void*)ctx->d_materials, (void*)ctx->d_plights, (void*)ctx->d_dlights, (void*)ctx->d_qlights,
+                    (void*)ctx->qcount, (void*)ctx->counters})
+        if (p) (void)hipFree(p);
+    if (ctx->h_count) (void)hipHostFree(ctx->h_count);
+    for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return PTC_OK;
+}
+
+const char* ptc_last_error(const ptc_context* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+int ptc_set_config(ptc_context* ctx, const PtcConfig* cfg) {
+    ENTER();
+    if (!cfg) return fail(ctx, PTC_ERR_INVALID, "null config");
+    ctx->cfg = *cfg;
+    ctx->next_event_est = cfg->next_event_est;
+    ctx->have_cfg = true;
+    return PTC_OK;
+}
+
+int ptc_set_integrator(ptc_context* ctx, const char* name) {
+    ENTER();
+    if (!name) return fail(ctx, PTC_ERR_INVALID, "null integrator name");
+    for (int i = 0; i < 5; ++i)
+        if (std::strcmp(name, kIntegrators[i]) == 0) {
+            ctx->integrator = i;
+            return PTC_OK;
+        }
+    return fail(ctx, PTC_ERR_INTEGRATOR, std::string("Doesn't support the integrator ") + name);
+}
+
+int ptc_set_params(ptc_context* ctx, uint32_t light_samples, uint32_t light_stratify, uint32_t next_event_est, uint32_t sampling_method, int32_t spp) {
+    ENTER();
+    if (spp < 0) return fail(ctx, PTC_ERR_INVALID, "samples_per_pixel must be >= 0");
+    if (light_samples > (1u << 20)) return fail(ctx, PTC_ERR_INVALID, "light_samples too large");
+    ctx->light_samples = light_samples;
+    ctx->light_stratify = light_stratify;
+    ctx->next_event_est = next_event_est;
+    ctx->sampling_method = sampling_method;
+    ctx->spp = spp;
+    return PTC_OK;
+}
+
+int ptc_set_triangles(ptc_context* ctx, const PtcTriangle* tris, size_t n) {
+    ENTER();
+    if (n && !tris) return fail(ctx, PTC_ERR_INVALID, "null triangle array");
+    if (n > (1u << 27) - 1) return fail(ctx, PTC_ERR_INVALID, "too many triangles");
+    ctx->tris.assign(tris, tris + n);
+    ctx->built = false;
+    return PTC_OK;
+}
+
+int ptc_set_spheres(ptc_context* ctx, const PtcSphere* sph, size_t n) {
+    ENTER();
+    if (n && !sph) return fail(ctx, PTC_ERR_INVALID, "null sphere array");
+    if (n > (1u << 27) - 1) return fail(ctx, PTC_ERR_INVALID, "too many spheres");
+    ctx->spheres.assign(sph, sph + n);
+    ctx->built = false;
+    return PTC_OK;
+}
+
+int ptc_set_lights(ptc_context* ctx, const PtcPointLight* pl, size_t np, const PtcDirectionalLight* dl, size_t nd, const PtcQuadLight* ql, size_t nq) {
+    ENTER();
+    if ((np && !pl) || (nd && !dl) || (nq && !ql)) return fail(ctx, PTC_ERR_INVALID, "null light array");
+    if (np + nd > 4096 || nq > 4096) return fail(ctx, PTC_ERR_INVALID, "too many lights");
+    ctx->plights.assign(pl, pl + np);
+    ctx->dlights.assign(dl, dl + nd);
+    ctx->qlights.assign(ql, ql + nq);
+    ctx->lights_dirty = true;
+    return PTC_OK;
+}
+
+int ptc_set_background(ptc_context* ctx, float r, float g, float b) {
+    ENTER();
+    ctx->bg[0] = r;
+    ctx->bg[1] = g;
+    ctx->bg[2] = b;
+    return PTC_OK;
+}
+
+int ptc_build(ptc_context* ctx) {
+    ENTER();
+    CHK(hipStreamSynchronize(ctx->stream));
+    hipEvent_t e0, e1;
+    CHK(hipEventCreate(&e0));
+    CHK(hipEventCreate(&e1));
+    CHK(hipEventRecord(e0, ctx->stream));
+    // de-duplicate the per-primitive material copies
+    std::map<std::string, uint32_t> ids;
+    std::vector<PtcMaterialValue> mats;
+    ctx->non_diffuse = false;
+    auto matId = [&](const PtcMaterialValue& mv, int objType) {
+        std::string key((const char*)&mv, sizeof(mv));
+        auto it = ids.find(key);
+        uint32_t id;
+        if (it == ids.end()) {
+            id = (uint32_t)mats.size();
+            ids.emplace(key, id);
+            mats.push_back(mv);
+        } else {
+            id = it->second;
+        }
+        if (mv.matType != PTC_DIFFUSE) ctx->non_diffuse = true;
+        return id | (objType == PTC_LIGHT ? MAT_LIGHT_BIT : 0u);
+    };
+    std::vector<uint32_t> tmat(ctx->tris.size()), smat(ctx->spheres.size());
+    for (size_t i = 0; i < ctx->tris.size(); ++i) tmat[i] = matId(ctx->tris[i].mv, ctx->tris[i].objType);
+    // spheres always report objectType OBJECT (Sphere.cu:55)
+    for (size_t i = 0; i < ctx->spheres.size(); ++i) smat[i] = matId(ctx->spheres[i].mv, PTC_OBJECT);
+    CHK(upload(ctx->d_materials, mats, ctx->stream));
+    CHK(upload(ctx->d_tris, ctx->tris, ctx->stream));
+    CHK(upload(ctx->d_spheres, ctx->spheres, ctx->stream));
+    bvh_free(ctx->bvh);
+    BvhBuildInput in{};
+    in.d_tris = ctx->d_tris;
+    in.n_tris = (uint32_t)ctx->tris.size();
+    in.d_spheres = ctx->d_spheres;
+    in.n_spheres = (uint32_t)ctx->spheres.size();
+    in.h_tri_mat = tmat.data();
+    in.h_sph_mat = smat.data();
+    in.extra_extent = ctx->have_cfg ? std::max(fabsf(ctx->cfg.eye.x), std::max(fabsf(ctx->cfg.eye.y), fabsf(ctx->cfg.eye.z))) : 0.f;
+    std::string err = bvh_build(ctx->stream, in, ctx->bvh);
+    if (!err.empty()) {
+        bvh_free(ctx->bvh);
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        return fail(ctx, PTC_ERR_DEVICE, err);
+    }
+    CHK(hipEventRecord(e1, ctx->stream));
+    CHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    ctx->stats.build_ms = ms;
+    ctx->stats.bvh_nodes = ctx->bvh.n_nodes;
+    ctx->stats.bvh_max_depth = ctx->bvh.max_depth;
+    ctx->built = true;
+    return PTC_OK;
+}
+
+int ptc_render_range(ptc_context* ctx, int frame_id, uint32_t width, uint32_t height, int32_t spp_begin, int32_t spp_end, int clear) {
+    ENTER();
+    return renderRange(ctx, frame_id, width, height, spp_begin, spp_end, clear);
+}
+
+int ptc_resolve(ptc_context* ctx, int frame_id, int32_t total_spp) {
+    ENTER();
+    if (!ctx->width) return fail(ctx, PTC_ERR_INVALID, "nothing rendered yet");
+    if (!ctx->have_cfg) return fail(ctx, PTC_ERR_INVALID, "ptc_set_config has not been called");
+    wf_resolve(ctx->stream, ctx->acc, ctx->result, ctx->width * ctx->height, total_spp, ctx->cfg.gamma, frame_id);
+    CHK(hipGetLastError());
+    return PTC_OK;
+}
+
+int ptc_render(ptc_context* ctx, int frame_id, uint32_t width, uint32_t height) {
+    ENTER();
+    int rc = renderRange(ctx, frame_id, width, height, 0, ctx->spp, 1);
+    if (rc) return rc;
+    rc = ptc_resolve(ctx, frame_id, ctx->spp);
+    if (rc) return rc;
+    CHK(hipStreamSynchronize(ctx->stream));
+    return PTC_OK;
+}
+
+int ptc_primary_hits(ptc_context* ctx, uint32_t width, uint32_t height, PtcHitRecord* out) {
+    ENTER();
+    if (!out) return fail(ctx, PTC_ERR_INVALID, "null output");
+    RenderParams rp;
+    const int saved = ctx->integrator;
+    if (ctx->integrator < 0) ctx->integrator = INT_RAYTRACER;
+    const bool nd = ctx->non_diffuse;
+    ctx->non_diffuse = false;  // only intersection runs here
+    int rc = makeParams(ctx, 1, width, height, rp);
+    ctx->integrator = saved;
+    ctx->non_diffuse = nd;
+    if (rc) return rc;
+    rp.seeding = 1;  // leaves the per-pixel segment counters untouched
+    rc = ensureTargets(ctx, width, height);
+    if (rc) return rc;
+    rc = ensurePaths(ctx, ctx->npix_pad, 0);
+    if (rc) return rc;
+    const DevScene sc = deviceScene(ctx);
+    CHK(hipMemsetAsync(ctx->qcount, 0, 2 * sizeof(uint32_t), ctx->stream));
+    CHK(hipMemsetAsync(ctx->ps.hit_ref, 0xFF, (size_t)ctx->npix_pad * sizeof(int32_t), ctx->stream));  // HIT_MISS
+    wf_generate(ctx->stream, rp, ctx->ps, ctx->npix_pad, ctx->npix_pad, 0u, ctx->acc, ctx->segctr, 0, ctx->queue[0], ctx->qcount);
+    CHK(hipMemcpyAsync(ctx->h_count, ctx->qcount, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    CHK(hipStreamSynchronize(ctx->stream));
+    wf_extend(ctx->stream, rp, sc, ctx->ps, ctx->queue[0], *ctx->h_count, false, ctx->counters);
+    wf_hit_records(ctx->stream, rp, sc, ctx->ps, ctx->npix_pad, ctx->d_hits);
+    CHK(hipMemcpyAsync(out, ctx->d_hits, (size_t)width * height * sizeof(PtcHitRecord), hipMemcpyDeviceToHost, ctx->stream));
+    CHK(hipStreamSynchronize(ctx->stream));
+    CHK(hipGetLastError());
+    return PTC_OK;
+}
+
+int ptc_read_result(ptc_context* ctx, float* rgb_out) {
+    ENTER();
+    if (!rgb_out || !ctx->width) return fail(ctx, PTC_ERR_INVALID, "nothing to read");
+    CHK(hipMemcpyAsync(rgb_out, ctx->result, (size_t)ctx->width * ctx->height * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    CHK(hipStreamSynchronize(ctx->stream));
+    return PTC_OK;
+}
+
+int ptc_read_sum(ptc_context* ctx, float* rgb_out) {
+    ENTER();
+    if (!rgb_out || !ctx->width) return fail(ctx, PTC_ERR_INVALID, "nothing to read");
+    CHK(hipMemcpyAsync(rgb_out, ctx->acc, (size_t)ctx->width * ctx->height * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    CHK(hipStreamSynchronize(ctx->stream));
+    return PTC_OK;
+}
+
+int ptc_bind_sum_buffer(ptc_context* ctx, void* device_ptr, size_t bytes) {
+    ENTER();
+    if (device_ptr && ctx->width && bytes < (size_t)ctx->width * ctx->height * 3 * sizeof(float))
+        return fail(ctx, PTC_ERR_INVALID, "sum buffer too small for the current image");
+    ctx->acc_ext = device_ptr;
+    ctx->acc_ext_bytes = bytes;
+    if (ctx->width) ctx->acc = device_ptr ? (float*)device_ptr : ctx->acc_own;
+    return PTC_OK;
+}
+
+int ptc_set_stream(ptc_context* ctx, void* hip_stream) {
+    ENTER();
+    CHK(hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return PTC_OK;
+}
+
+int ptc_synchronize(ptc_context* ctx) {
+    ENTER();
+    CHK(hipStreamSynchronize(ctx->stream));
+    return PTC_OK;
+}
+
+int ptc_set_option(ptc_context* ctx, int option, int64_t value) {
+    ENTER();
+    switch (option) {
+        case PTC_OPT_SEMANTICS:
+            if (value != 0 && value != 1) return fail(ctx, PTC_ERR_INVALID, "semantics must be 0 or 1");
+            ctx->semantics = (int)value;
+            break;
+        case PTC_OPT_SEEDING:
+            if (value != 0 && value != 1) return fail(ctx, PTC_ERR_INVALID, "seeding must be 0 or 1");
+            ctx->seeding = (int)value;
+            break;
+        case PTC_OPT_BOUNCE_CAP:
+            if (value < 1 || value > 4096) return fail(ctx, PTC_ERR_INVALID, "bounce cap must be 1..4096");
+            ctx->bounce_cap = (uint32_t)value;
+            break;
+        case PTC_OPT_CULL_ZERO: ctx->cull_zero = value != 0; break;
+        case PTC_OPT_BATCH_PATHS:
+            if (value < 1) return fail(ctx, PTC_ERR_INVALID, "batch size must be positive");
+            ctx->batch_paths = (uint64_t)value;
+            break;
+        case PTC_OPT_PROFILE: ctx->profile = value != 0; break;
+        case PTC_OPT_COUNT_TRAVERSAL: ctx->count_trav = value != 0; break;
+        case PTC_OPT_BRUTE_FORCE: ctx->brute_force = value != 0; break;
+        default: return fail(ctx, PTC_ERR_INVALID, "unknown option");
+    }
+    return PTC_OK;
+}
+
+int ptc_get_stats(ptc_context* ctx, PtcStats* out) {
+    ENTER();
+    if (!out) return fail(ctx, PTC_ERR_INVALID, "null output");
+    CHK(hipStreamSynchronize(ctx->stream));
+    collectSpans(ctx);
+    unsigned long long h[8];
+    CHK(hipMemcpy(h, ctx->counters, sizeof(h), hipMemcpyDeviceToHost));
+    ctx->stats.nodes_visited = h[0];
+    ctx->stats.prims_tested = h[1];
+    ctx->stats.shadow_nodes_visited = h[2];
+    ctx->stats.shadow_prims_tested = h[3];
+    ctx->stats.shadow_rays = h[4];
+    *out = ctx->stats;
+    return PTC_OK;
+}
+
+int ptc_reset_stats(ptc_context* ctx) {
+    ENTER();
+    CHK(hipStreamSynchronize(ctx->stream));
+    collectSpans(ctx);
+    CHK(hipMemset(ctx->counters, 0, 8 * sizeof(unsigned long long)));
+    const double build_ms = ctx->stats.build_ms;
+    const uint32_t nodes = ctx->stats.bvh_nodes, depth = ctx->stats.bvh_max_depth;
+    ctx->stats = PtcStats{};
+    ctx->stats.build_ms = build_ms;
+    ctx->stats.bvh_nodes = nodes;
+    ctx->stats.bvh_max_depth = depth;
+    return PTC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,49 @@
+// wavefront.h -- host-side launchers of the wavefront kernels (wavefront.hip)
+// and of the GPU BVH build (bvh_build.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "device_scene.h"
+
+void wf_generate(hipStream_t s, const RenderParams& rp, const PathState& ps, uint32_t npix_pad, uint32_t n_paths, uint32_t sample_begin,
+                 const float* acc, uint32_t* segctr, int seed_L_from_acc, uint32_t* queue, uint32_t* qcount);
+void wf_extend(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, uint32_t count, bool count_trav,
+               unsigned long long* trav_counters);
+void wf_connect(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, uint32_t count, uint32_t n_samples,
+                bool count_trav, unsigned long long* trav_counters, unsigned long long* shadow_counter);
+void wf_shade(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, uint32_t count, uint32_t npix_pad,
+              uint32_t sample_begin, uint32_t* segctr, uint32_t* next_queue, uint32_t* next_count);
+void wf_accumulate(hipStream_t s, const RenderParams& rp, const PathState& ps, uint32_t npix_pad, uint32_t n_samples, float* acc, int replace);
+void wf_resolve(hipStream_t s, const float* acc, float* result, uint32_t n_pixels, int spp, float gamma, int frame_id);
+void wf_hit_records(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, uint32_t npix_pad, PtcHitRecord* out);
+
+// ---- BVH build (bvh_build.hip) ----------------------------------------------
+struct BvhBuildInput {
+    const PtcTriangle* d_tris;   // device copies of the AoS uploads
+    uint32_t n_tris;
+    const PtcSphere* d_spheres;
+    uint32_t n_spheres;
+    const uint32_t* h_tri_mat;   // host: material id | light bit per triangle / sphere (upload order)
+    const uint32_t* h_sph_mat;
+    float extra_extent;          // |coordinate| bound of ray origins outside the geometry (the eye)
+};
+
+struct BvhBuildOutput {  // device allocations owned by the caller afterwards
+    float4* tri_q = nullptr;
+    uint32_t* tri_mat = nullptr;
+    int32_t* tri_prim = nullptr;
+    DevSphere* spheres = nullptr;
+    uint32_t* sph_mat = nullptr;
+    int32_t* sph_prim = nullptr;
+    BvhNode* nodes = nullptr;
+    uint32_t n_nodes = 0;
+    uint32_t max_depth = 0;
+};
+
+// Returns an empty string on success, else an error message.
+std::string bvh_build(hipStream_t s, const BvhBuildInput& in, BvhBuildOutput& out);
+void bvh_free(BvhBuildOutput& out);

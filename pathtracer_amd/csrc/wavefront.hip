@@ -1,0 +1,712 @@
+// wavefront.hip -- the wavefront path-tracing kernels for gfx950.
+//
+//   k_generate   camera rays for a batch of (pixel, sample) paths
+//                (PinholeCamera.cu:37-51), 8x8 pixel tile per 64-lane wave
+//   k_extend     closest hit of every active path (rtTrace ray type 0:
+//                Triangle.cu / Sphere.cu over the BVH), LDS-resident stack
+//   k_connect    one thread per shadow ray of the segment (rtTrace ray type 1,
+//                any-hit of Common.cu:30-36) leaving the f*G term of that light
+//                sample, or 0 when occluded
+//   k_shade      the closest-hit program of the chosen integrator
+//                (RayTracer.cu) + the bounce-loop bookkeeping of
+//                PinholeCamera.cu:54-66; survivors are compacted into the next
+//                queue with a wave64 ballot / prefix count / one atomic per wave
+//   k_accumulate per-pixel sum of the batch's samples, in sample order
+//   k_resolve    average, gamma, frame lerp (PinholeCamera.cu:70-80)
+//
+// All arithmetic that decides a hit (t,u,v) is plain IEEE fp32 in the
+// reference's operation order; compile with -ffp-contract=off.
+#include <hip/hip_runtime.h>
+
+#include "device_scene.h"
+#include "intersect.h"
+#include "shading.h"
+#include "wavefront.h"
+
+#define BLOCK TRAV_BLOCK
+
+// ---------------------------------------------------------------- helpers --
+
+__device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
+__device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
+
+// Map a padded pixel number to image coordinates: 64 consecutive numbers form
+// an 8x8 tile, so one wave traces a compact bundle of camera rays.
+__device__ __forceinline__ bool pixel_of(const RenderParams& rp, uint32_t pix, uint32_t& x, uint32_t& y) {
+    const uint32_t tiles_x = (rp.width + 7u) >> 3;
+    const uint32_t tile = pix >> 6, in = pix & 63u;
+    x = (tile % tiles_x) * 8u + (in & 7u);
+    y = (tile / tiles_x) * 8u + (in >> 3);
+    return x < rp.width && y < rp.height;
+}
+
+// Append `value` for every lane with keep=true; one atomic per wave.  Must be
+// reached by all lanes of the wave that are still running.
+__device__ __forceinline__ void queue_append(bool keep, uint32_t value, uint32_t* __restrict__ out, uint32_t* __restrict__ counter) {
+    const unsigned long long mask = __ballot(keep);
+    if (mask == 0ull) return;
+    const uint32_t lane = __lane_id();
+    const uint32_t prefix = __popcll(mask & ((1ull << lane) - 1ull));
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    if (keep) out[base + prefix] = value;
+}
+
+__device__ __forceinline__ uint32_t segment_seed(const RenderParams& rp, uint32_t key0, uint32_t sample, uint32_t bounce, uint32_t* segctr, uint32_t pix) {
+    if (rp.seeding == 0) {  // PinholeCamera.cu:56, i++ over the pixel's whole history
+        uint32_t i = segctr[pix];
+        segctr[pix] = i + 1u;
+        return tea16(key0, i);
+    }
+    return tea16(key0, (sample << 12) | bounce);
+}
+
+// ---------------------------------------------------------------- generate --
+__global__ __launch_bounds__(BLOCK) void k_generate(RenderParams rp, PathState ps, uint32_t npix_pad, uint32_t n_paths, uint32_t sample_begin,
+                                                    const float* __restrict__ acc, uint32_t* __restrict__ segctr, int seed_L_from_acc,
+                                                    uint32_t* __restrict__ queue, uint32_t* __restrict__ qcount) {
+    const uint32_t p = blockIdx.x * BLOCK + threadIdx.x;
+    bool valid = p < n_paths;
+    uint32_t x = 0, y = 0, pix = 0, j = 0;
+    if (valid) {
+        pix = p % npix_pad;
+        j = sample_begin + p / npix_pad;
+        valid = pixel_of(rp, pix, x, y);
+    }
+    if (valid) {
+        const PtcConfig& cf = rp.cf;
+        const uint32_t index = x * rp.height + y;  // PinholeCamera.cu:23
+        const uint32_t key0 = index * rp.frame_id;
+        float jx = 0.5f, jy = 0.5f;  // :47-48
+        if (j != 0) {
+            uint32_t st = lcg_skip(tea16(key0, 0u), 2u * (j - 1u));
+            jx = rnd(st);
+            jy = rnd(st);
+        }
+        const float px = (float)x + jx, py = (float)y + jy;
+        const float abx = cf.tanHFov.x * (px - cf.hSize.x) / cf.hSize.x;  // :49
+        const float aby = cf.tanHFov.y * (py - cf.hSize.y) / cf.hSize.y;
+        const vec3 dir = normalize(abx * P3v(cf.u) + aby * P3v(cf.v) - P3v(cf.w));  // :51
+        const uint32_t seed = segment_seed(rp, key0, j, 0u, segctr, pix);
+        ps.o_seed[p] = make_float4(cf.eye.x, cf.eye.y, cf.eye.z, u2f(seed));
+        ps.d_depth[p] = make_float4(dir.x, dir.y, dir.z, u2f(0u));
+        ps.thr[p] = make_float4(1.f, 1.f, 1.f, u2f(0u));
+        float4 L = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (seed_L_from_acc) {
+            const float* a = acc + 3 * ((size_t)y * rp.width + x);
+            L = make_float4(a[0], a[1], a[2], 0.f);
+        }
+        ps.L[p] = L;
+    }
+    queue_append(valid, p, queue, qcount);
+}
+
+// ------------------------------------------------------------------ extend --
+template <bool COUNT>
+__global__ __launch_bounds__(BLOCK) void k_extend(RenderParams rp, DevScene sc, PathState ps, const uint32_t* __restrict__ queue, uint32_t count,
+                                                  unsigned long long* __restrict__ trav_counters) {
+    __shared__ uint32_t stack[TRAV_LDS_STACK * BLOCK];
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t p = queue[i];
+    const float4 o4 = ps.o_seed[p], d4 = ps.d_depth[p];
+    const vec3 o = mk3(o4.x, o4.y, o4.z), d = mk3(d4.x, d4.y, d4.z);
+    ClosestHit best;
+    TravCounters cnt = {0u, 0u};
+    if (rp.brute_force)
+        brute_force<false>(sc, o, d, rp.cf.epsilon, PT_RAY_MAX, best);
+    else
+        traverse<false, COUNT>(sc, o, d, rp.cf.epsilon, PT_RAY_MAX, stack + threadIdx.x, best, cnt);
+    ps.hit_t[p] = best.t;
+    ps.hit_ref[p] = best.ref;
+    if (COUNT) {
+        atomicAdd(&trav_counters[0], (unsigned long long)cnt.nodes);
+        atomicAdd(&trav_counters[1], (unsigned long long)cnt.prims);
+    }
+}
+
+// ----------------------------------------------------------------- connect --
+// Material access helpers.
+__device__ __forceinline__ const PtcMaterialValue& material_of(const DevScene& sc, uint32_t mat) { return sc.materials[mat & ~MAT_LIGHT_BIT]; }
+__device__ __forceinline__ bool is_light(uint32_t mat) { return (mat & MAT_LIGHT_BIT) != 0u; }
+
+template <int INTEG, bool COUNT>
+__global__ __launch_bounds__(BLOCK) void k_connect(RenderParams rp, DevScene sc, PathState ps, const uint32_t* __restrict__ queue, uint32_t count,
+                                                   uint32_t n_samples, unsigned long long* __restrict__ trav_counters,
+                                                   unsigned long long* __restrict__ shadow_counter) {
+    __shared__ uint32_t stack[TRAV_LDS_STACK * BLOCK];
+    const uint64_t tid = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (tid >= (uint64_t)count * n_samples) return;
+    const uint32_t i = (uint32_t)(tid % count), q = (uint32_t)(tid / count);
+    const uint32_t p = queue[i];
+    float* out = ps.contrib + (size_t)q * 3u * ps.capacity + p;
+    vec3 term = mk3(0.f);
+    const int ref = ps.hit_ref[p];
+    bool traced = false;
+    if (ref != HIT_MISS) {
+        const float4 o4 = ps.o_seed[p], d4 = ps.d_depth[p];
+        const vec3 o = mk3(o4.x, o4.y, o4.z), d = mk3(d4.x, d4.y, d4.z);
+        const uint32_t seed = f2u(o4.w), depth = f2u(d4.w);
+        HitAttr at;
+        hit_attributes(sc, ref, ps.hit_t[p], o, d, at);
+        const PtcMaterialValue& mv = material_of(sc, at.mat);
+        const PtcConfig& cf = rp.cf;
+        bool skip = false;
+        if (INTEG == INT_DIRECT) skip = is_light(at.mat);                                   // RayTracer.cu:160-165
+        if (INTEG == INT_PATHTRACER) skip = cf.next_event_est && is_light(at.mat) && depth != 0u;  // :528-533
+        if (INTEG == INT_PATHTRACER2) skip = depth > 0u && is_light(at.mat);               // :436-441
+        if (!skip) {
+            vec3 sh_o, sh_d;
+            float sh_tmin = cf.epsilon, sh_tmax;
+            vec3 light_pos = mk3(0.f);
+            QuadFrame qf;
+            uint32_t k = 0;
+            if (INTEG == INT_RAYTRACER) {
+                // RayTracer.cu:42-86: point lights, then directional lights
+                if (q < sc.n_plights) {
+                    const vec3 loc = P3v(sc.plights[q].location);
+                    sh_d = normalize(loc - at.P);
+                    sh_tmax = length(loc - at.P);
+                } else {
+                    sh_d = P3v(sc.dlights[q - sc.n_plights].direction);
+                    sh_tmax = PT_RAY_MAX;
+                }
+                sh_o = at.P + sh_d * cf.epsilon;
+            } else {
+                const int root = (int)rp.root_light_samples;
+                const uint32_t per_light = (uint32_t)(root * root);
+                k = q / per_light;
+                const uint32_t r = q % per_light;
+                const int si = (int)(r / (uint32_t)root), sj = (int)(r % (uint32_t)root);
+                const PtcQuadLight& ql = sc.qlights[k];
+                qf.a = P3v(ql.tri1.v1);
+                const vec3 b = P3v(ql.tri1.v2);
+                // `c` is tri2.v3 in direct / pathTracer (:172,712) and tri1.v3 in
+                // computeDirectLight (:380); the loader stores the same point in both.
+                const vec3 c = INTEG == INT_PATHTRACER2 ? P3v(ql.tri1.v3) : P3v(ql.tri2.v3);
+                qf.ab = b - qf.a;
+                qf.ac = c - qf.a;
+                // random numbers of this sample: position in the segment's LCG stream
+                const uint32_t lead = INTEG == INT_PATHTRACER ? 3u : 0u;  // zeta_0..2 come first (:537-539)
+                uint32_t st = lcg_skip(seed, lead + 2u * q);
+                const float u1 = rnd(st);
+                const float u2 = rnd(st);
+                light_pos = quad_sample(qf, rp.light_stratify != 0u, si, sj, root, u1, u2, INTEG == INT_PATHTRACER2);
+                sh_o = at.P;
+                sh_d = normalize(light_pos - sh_o);
+                sh_tmax = length(light_pos - sh_o) - cf.epsilon;
+            }
+            ClosestHit tmp;
+            TravCounters cnt = {0u, 0u};
+            bool occluded;
+            if (rp.brute_force)
+                occluded = brute_force<true>(sc, sh_o, sh_d, sh_tmin, sh_tmax, tmp);
+            else
+                occluded = traverse<true, COUNT>(sc, sh_o, sh_d, sh_tmin, sh_tmax, stack + threadIdx.x, tmp, cnt);
+            traced = true;
+            if (COUNT) {
+                atomicAdd(&trav_counters[2], (unsigned long long)cnt.nodes);
+                atomicAdd(&trav_counters[3], (unsigned long long)cnt.prims);
+            }
+            if (!occluded) {
+                if (INTEG == INT_RAYTRACER) {
+                    const vec3 H = normalize(sh_d + at.wo);
+                    vec3 I = P3v(mv.diffuse) * fmaxf(dot(at.normal, sh_d), 0);
+                    I += P3v(mv.specular) * powf(fmaxf(dot(at.normal, H), 0), mv.shininess);
+                    if (q < sc.n_plights) {
+                        const float lightDist = sh_tmax;
+                        const float att = dot(P3v(sc.plights[q].attenuation), mk3(1, lightDist, lightDist * lightDist));
+                        I *= P3v(sc.plights[q].color) / att;
+                    } else {
+                        I *= P3v(sc.dlights[q - sc.n_plights].color);
+                    }
+                    term = I;
+                } else if (INTEG == INT_DIRECT) {
+                    // RayTracer.cu:204-221
+                    const vec3 wdir = normalize(light_pos - sh_o);
+                    const vec3 f_brdf = (P3v(mv.diffuse) / PT_PIf) +
+                                        (P3v(mv.specular) * ((mv.shininess + 2.0f) / (2.0f * PT_PIf)) *
+                                         powf(fmaxf(dot(normalize(reflect(-at.wo, at.normal)), wdir), .0f), mv.shininess));
+                    const vec3 n_light = normalize(cross(qf.ab, qf.ac));
+                    const float R = length(sh_o - light_pos);
+                    const float G = (1.0f / powf(R, 2.0f)) * fmaxf(dot(at.normal, normalize(light_pos - sh_o)), .0f) *
+                                    (fmaxf(dot(n_light, normalize(light_pos - sh_o)), .0f));
+                    term = f_brdf * G;
+                } else if (INTEG == INT_PATHTRACER) {
+                    // RayTracer.cu:745-776
+                    const vec3 n = normalize(at.normal);
+                    const vec3 r = normalize(reflect(-at.wo, at.normal));
+                    const vec3 w_i_dir = normalize(light_pos - sh_o);
+                    vec3 f_brdf = mk3(.0f);
+                    if (mv.brdf_type == PTC_MOD_PHONG) {
+                        f_brdf = phong_brdf(w_i_dir, r, mv.shininess, P3v(mv.diffuse), P3v(mv.specular));
+                    } else {
+                        const float wi_dot_n_dir = dot(w_i_dir, n);
+                        const float wo_dot_n_dir = dot(at.wo, n);
+                        if (wi_dot_n_dir > .0f && wo_dot_n_dir > .0f) {
+                            const vec3 f_brdf_GGX = ggx_brdf(w_i_dir, at.wo, n, mv.roughness, P3v(mv.specular));
+                            f_brdf = (P3v(mv.diffuse) / PT_PIf) + f_brdf_GGX;
+                        }
+                    }
+                    const vec3 n_geo = at.normal;  // the inner `n` of :767, not normalised
+                    const vec3 n_light = normalize(cross(qf.ab, qf.ac));
+                    const float R = length(sh_o - light_pos);
+                    const float G = (1.0f / powf(R, 2.0f)) * fmaxf(dot(n_geo, normalize(light_pos - sh_o)), .0f) *
+                                    (fmaxf(dot(n_light, normalize(light_pos - sh_o)), .0f));
+                    term = f_brdf * G;
+                } else if (INTEG == INT_PATHTRACER2) {
+                    // RayTracer.cu:410-420
+                    const float dist = length(light_pos - at.P);
+                    const vec3 n_light = normalize(cross(qf.ab, qf.ac));
+                    const vec3 reflect_dir = reflect(-at.wo, at.normal);
+                    const float G = (1.0f / (dist * dist)) * fmaxf(dot(at.normal, sh_d), .0f) * fmaxf(dot(n_light, sh_d), .0f);
+                    const vec3 f_brdf = phong_brdf(sh_d, reflect_dir, mv.shininess, P3v(mv.diffuse), P3v(mv.specular));
+                    term = f_brdf * G;
+                }
+            }
+        }
+    }
+    out[0] = term.x;
+    out[ps.capacity] = term.y;
+    out[2u * (size_t)ps.capacity] = term.z;
+    // one atomic per wave for the shadow-ray count
+    const unsigned long long m = __ballot(traced);
+    if (m && __lane_id() == (uint32_t)(__ffsll((long long)m) - 1)) atomicAdd(shadow_counter, (unsigned long long)__popcll(m));
+}
+
+// ------------------------------------------------------------------- shade --
+struct Segment {
+    vec3 o, d, thr;
+    uint32_t depth, seed;
+    bool done;
+};
+
+__device__ __forceinline__ vec3 contrib_at(const PathState& ps, uint32_t p, uint32_t q) {
+    const float* c = ps.contrib + (size_t)q * 3u * ps.capacity + p;
+    return mk3(c[0], c[ps.capacity], c[2u * (size_t)ps.capacity]);
+}
+
+// RayTracer.cu:34-105
+__device__ __forceinline__ vec3 shade_raytracer(const RenderParams& rp, const DevScene& sc, const PathState& ps, uint32_t p, const HitAttr& at, Segment& sg) {
+    const PtcMaterialValue& mv = material_of(sc, at.mat);
+    vec3 result = P3v(mv.ambient) + P3v(mv.emission);
+    const uint32_t nl = sc.n_plights + sc.n_dlights;
+    for (uint32_t q = 0; q < nl; ++q) result += contrib_at(ps, p, q);  // occluded lights left 0
+    const vec3 radiance = result * sg.thr;
+    if (length(P3v(mv.specular)) > 0) {
+        sg.o = at.P;
+        sg.d = reflect(-at.wo, at.normal);
+        sg.depth++;
+        sg.thr *= P3v(mv.specular);
+    } else {
+        sg.done = true;
+    }
+    return radiance;
+}
+
+// RayTracer.cu:107-151
+__device__ __forceinline__ vec3 shade_analytic(const RenderParams& rp, const DevScene& sc, const HitAttr& at, Segment& sg) {
+    const PtcMaterialValue& mv = material_of(sc, at.mat);
+    vec3 result = P3v(mv.ambient) + P3v(mv.emission);
+    if (rp.light_samples == 0u) {
+        for (uint32_t i = 0; i < sc.n_qlights; ++i) {
+            const vec3 f_brdf = P3v(mv.diffuse) / PT_PIf;
+            const vec3 hitPt = at.P, hitPtNormal = at.normal;
+            const PtcQuadLight& q = sc.qlights[i];
+            const vec3 p1 = P3v(q.tri1.v1), p2 = P3v(q.tri1.v2), p3 = P3v(q.tri2.v2), p4 = P3v(q.tri1.v3);
+            const float theta_1 = acosf(dot(normalize(p1 - hitPt), normalize(p2 - hitPt)));
+            const float theta_2 = acosf(dot(normalize(p2 - hitPt), normalize(p3 - hitPt)));
+            const float theta_3 = acosf(dot(normalize(p3 - hitPt), normalize(p4 - hitPt)));
+            const float theta_4 = acosf(dot(normalize(p4 - hitPt), normalize(p1 - hitPt)));
+            const vec3 gamma_1 = normalize(cross((p1 - hitPt), (p2 - hitPt)));
+            const vec3 gamma_2 = normalize(cross((p2 - hitPt), (p3 - hitPt)));
+            const vec3 gamma_3 = normalize(cross((p3 - hitPt), (p4 - hitPt)));
+            const vec3 gamma_4 = normalize(cross((p4 - hitPt), (p1 - hitPt)));
+            const vec3 irradiance_vec = 0.5f * ((theta_1 * gamma_1) + (theta_2 * gamma_2) + (theta_3 * gamma_3) + (theta_4 * gamma_4));
+            result += f_brdf * P3v(q.color) * dot(irradiance_vec, hitPtNormal);
+        }
+    }
+    sg.done = true;
+    return result;
+}
+
+// Sum of the light-sample terms of quad light k in loop order.
+__device__ __forceinline__ vec3 light_sum(const PathState& ps, uint32_t p, uint32_t k, uint32_t per_light) {
+    vec3 s = mk3(.0f);
+    for (uint32_t r = 0; r < per_light; ++r) s += contrib_at(ps, p, k * per_light + r);
+    return s;
+}
+
+__device__ __forceinline__ float quad_area(const PtcQuadLight& ql, bool cdl) {
+    const vec3 a = P3v(ql.tri1.v1), b = P3v(ql.tri1.v2), c = cdl ? P3v(ql.tri1.v3) : P3v(ql.tri2.v3);
+    return length(cross(b - a, c - a));
+}
+
+// RayTracer.cu:153-230
+__device__ __forceinline__ vec3 shade_direct(const RenderParams& rp, const DevScene& sc, const PathState& ps, uint32_t p, const HitAttr& at, Segment& sg) {
+    const PtcMaterialValue& mv = material_of(sc, at.mat);
+    vec3 result = P3v(mv.ambient) + P3v(mv.emission);
+    sg.done = true;
+    if (is_light(at.mat)) {
+        sg.depth = rp.max_depth_eff;
+        return result;
+    }
+    const uint32_t per_light = rp.root_light_samples * rp.root_light_samples;
+    for (uint32_t k = 0; k < sc.n_qlights; ++k) {
+        const float area = fabsf(quad_area(sc.qlights[k], false));
+        result += P3v(sc.qlights[k].color) * light_sum(ps, p, k, per_light) * (area / (float)rp.light_samples);
+    }
+    return result;
+}
+
+// RayTracer.cu:429-494
+__device__ __forceinline__ vec3 shade_pathtracer2(const RenderParams& rp, const DevScene& sc, const PathState& ps, uint32_t p, const HitAttr& at, Segment& sg) {
+    const PtcMaterialValue& mv = material_of(sc, at.mat);
+    const vec3 L_e = P3v(mv.emission);
+    if (sg.depth > 0u && is_light(at.mat)) {
+        sg.depth = rp.max_depth_eff;
+        sg.done = true;
+        return mk3(.0f);
+    }
+    const uint32_t per_light = rp.root_light_samples * rp.root_light_samples;
+    vec3 L_d = mk3(.0f);
+    for (uint32_t k = 0; k < sc.n_qlights; ++k) {
+        const float area = fabsf(quad_area(sc.qlights[k], true));
+        L_d += P3v(sc.qlights[k].color) * (area / (float)rp.light_samples) * light_sum(ps, p, k, per_light);
+    }
+    uint32_t st = lcg_skip(sg.seed, 2u * per_light * sc.n_qlights);
+    const float zeta1 = rnd(st), zeta2 = rnd(st);
+    const float theta = acosf(zeta1), phi = 2.0f * PT_PIf * zeta2;
+    const vec3 w = normalize(at.normal);
+    vec3 a = mk3(0, 1, 0);
+    if (1.0f - fabsf(dot(a, w)) <= 1.0f) a = mk3(1, 0, 0);
+    const vec3 u = normalize(cross(a, w)), v = normalize(cross(w, u));
+    const vec3 w_i = normalize(spherical_dir(theta, phi, u, v, w));
+    const vec3 norm = normalize(at.normal);
+    const vec3 incoming_ray_dir = normalize(-at.wo);
+    const vec3 reflected_ray_dir = normalize(reflect(incoming_ray_dir, norm));
+    const vec3 f_brdf = phong_brdf(w_i, reflected_ray_dir, mv.shininess, P3v(mv.diffuse), P3v(mv.specular));
+    const float pdf = 1.0f / (2.0f * PT_PIf);
+    const vec3 attenuation = (f_brdf * fmaxf(dot(norm, w_i), .0f)) * (1.0f / pdf);
+    vec3 radiance = mk3(.0f);
+    if (sg.depth == 0u) radiance += L_e * sg.thr;
+    radiance += L_d * sg.thr;
+    sg.thr *= attenuation;
+    const float q = fminf(fmaxf(fmaxf(sg.thr.x, sg.thr.y), sg.thr.z), 1.0f);
+    if (rnd(st) > q) {
+        sg.depth = rp.max_depth_eff;
+        sg.done = true;
+        return radiance;
+    }
+    sg.thr *= 1.0f / (q);
+    sg.o = at.P;
+    sg.d = w_i;
+    sg.depth++;
+    return radiance;
+}
+
+// RayTracer.cu:496-963 for DIFFUSE materials.
+__device__ __forceinline__ vec3 shade_pathtracer(const RenderParams& rp, const DevScene& sc, const PathState& ps, uint32_t p, const HitAttr& at, Segment& sg) {
+    const PtcMaterialValue& mv = material_of(sc, at.mat);
+    const PtcConfig& cf = rp.cf;
+    vec3 result = mk3(.0f);
+    vec3 L_d = mk3(.0f);
+    const vec3 n = normalize(at.normal);
+    const vec3 L_e = P3v(mv.emission), K_s = P3v(mv.specular), K_d = P3v(mv.diffuse);
+    const vec3 r = normalize(reflect(-at.wo, at.normal));
+    float theta = .0f, phi = .0f;
+    const float exp_beta = 2.0f;
+    vec3 w_i = mk3(.0f);
+    vec3 addon_throughput = mk3(1.0f);
+
+    if (cf.next_event_est && is_light(at.mat) && sg.depth != 0u) {  // :528-533
+        sg.depth = rp.max_depth_eff;
+        sg.done = true;
+        return result;
+    }
+    uint32_t st = sg.seed;
+    const float zeta_0 = rnd(st), zeta_1 = rnd(st), zeta_2 = rnd(st);
+    const float K_s_avg = (K_s.x + K_s.y + K_s.z) / 3.0f;
+    const float K_d_avg = (K_d.x + K_d.y + K_d.z) / 3.0f;
+    float t = .0f;
+    if ((K_s_avg == .0f) && (K_d_avg == .0f)) {  // :546-553
+        if (mv.brdf_type == PTC_MOD_PHONG) t = .0f;
+        else if (mv.brdf_type == PTC_GGX) t = 1.0f;
+    } else {
+        const float k_val = K_s_avg / (K_s_avg + K_d_avg);
+        t = mv.brdf_type == PTC_MOD_PHONG ? k_val : fmaxf(.25f, k_val);
+    }
+    compute_polar_angles(rp.semantics, rp.sampling_method, phi, theta, zeta_0, zeta_1, zeta_2, t, mv.shininess);  // :566
+
+    if (mv.brdf_type == PTC_MOD_PHONG) {  // :675-684
+        const vec3 w = ((zeta_0 <= t) && (rp.sampling_method == PTC_BRDF_SAMPLING)) ? r : n;
+        vec3 u = mk3(.0f), v = mk3(.0f);
+        gen_coord_frame(rp.semantics, w, u, v);
+        w_i = spherical_dir(theta, phi, u, v, w);
+    } else {  // :685-696
+        const float theta_h_sample = atanf((mv.roughness * sqrtf(zeta_1)) / sqrtf(1.0f - zeta_1));
+        const float phi_h_sample = 2.0f * PT_PIf * zeta_2;
+        vec3 u_h = mk3(.0f), v_h = mk3(.0f);
+        gen_coord_frame(rp.semantics, n, u_h, v_h);
+        w_i = normalize(reflect(-at.wo, spherical_dir(theta_h_sample, phi_h_sample, u_h, v_h, n)));
+    }
+
+    if (cf.next_event_est) {  // :700-801
+        const uint32_t per_light = rp.root_light_samples * rp.root_light_samples;
+        for (uint32_t k = 0; k < sc.n_qlights; ++k) {
+            const vec3 sampled_result = light_sum(ps, p, k, per_light);
+            const float area = quad_area(sc.qlights[k], false);
+            if (cf.next_event_est == PTC_NEE_MIS) {
+                // :782-794 as written: pdf_lights_k, D and h are never assigned, so
+                // pdf_NEE = 0 and pdf_brdf carries a 0/0 term.
+                const float pdf_NEE = .0f, D = .0f;
+                const vec3 h = mk3(.0f), w_i_dir = mk3(.0f);
+                const float pdf_brdf = ((1.0f - t) * fmaxf(dot(n, w_i_dir), .0f) / PT_PIf) + ((t * D * dot(n, h)) / (4.0f * dot(h, w_i_dir)));
+                const float pdf_denom_sum = powf(pdf_NEE, exp_beta) + powf(pdf_brdf, exp_beta);
+                const float pdf_numerator = powf(pdf_NEE, exp_beta);
+                const float weight_i = pdf_numerator / pdf_denom_sum;
+                L_d += P3v(sc.qlights[k].color) * sampled_result * (area / (float)rp.light_samples) * (1.0f / pdf_NEE) * weight_i;
+            } else {
+                L_d += P3v(sc.qlights[k].color) * sampled_result * (area / (float)rp.light_samples);  // :798
+            }
+        }
+        st = lcg_skip(st, 2u * per_light * sc.n_qlights);  // the u1,u2 of every light sample
+    }
+
+    vec3 f_brdf = mk3(1.0f);
+    float pdf = 1.0f;
+    switch (rp.sampling_method) {  // :811-897
+        case PTC_HEMISPHERE_SAMPLING:
+            f_brdf = (P3v(mv.diffuse) / PT_PIf) + (P3v(mv.specular) * ((mv.shininess + 2.0f) / (2.0f * PT_PIf)) * powf(fmaxf(dot(r, w_i), .0f), mv.shininess));
+            pdf = 1.0f / (2.0f * PT_PIf);
+            addon_throughput = (f_brdf * fmaxf(dot(n, w_i), .0f) * (1.0f / pdf));
+            break;
+        case PTC_COSINE_SAMPLING:
+            f_brdf = (P3v(mv.diffuse) / PT_PIf) + (P3v(mv.specular) * ((mv.shininess + 2.0f) / (2.0f * PT_PIf)) * powf(fmaxf(dot(r, w_i), .0f), mv.shininess));
+            pdf = fmaxf(dot(n, w_i), .0f) / (PT_PIf);
+            addon_throughput = (f_brdf)*fmaxf(dot(n, w_i), .0f) * (1.0f / pdf);
+            break;
+        case PTC_BRDF_SAMPLING:
+            // The probe shadow rays of :831-860 only feed locals that are never read
+            // again; they cannot change the payload and are not traced.
+            if (mv.brdf_type == PTC_MOD_PHONG) {
+                f_brdf = phong_brdf(w_i, r, mv.shininess, K_d, K_s);
+                pdf = ((1.0f - t) * (dot(n, w_i) / PT_PIf)) + t * ((mv.shininess + 1.0f) / (2.0f * PT_PIf)) * powf(fmaxf(dot(r, w_i), .0f), mv.shininess);
+            } else {
+                const float wi_dot_n = dot(w_i, n);
+                const float wo_dot_n = dot(at.wo, n);
+                if (wi_dot_n > .0f && wo_dot_n > .0f) {
+                    const vec3 h = normalize(w_i + at.wo);
+                    f_brdf = (K_d / PT_PIf) + ggx_brdf(w_i, at.wo, n, mv.roughness, K_s);
+                    pdf = ggx_pdf(w_i, n, h, t, mv.roughness);
+                } else {
+                    f_brdf = mk3(.0f);
+                }
+            }
+            addon_throughput = (f_brdf * fmaxf(dot(n, w_i), .0f) * (1.0f / pdf));
+            break;
+        default:
+            break;
+    }
+
+    if (cf.next_event_est && (sg.depth == 0u)) result += L_e + L_d;  // :900-917
+    else if (cf.next_event_est == PTC_NEE_ON || cf.next_event_est == PTC_NEE_MIS) result += L_d;
+    else result += L_e;
+    const vec3 radiance = result * sg.thr;  // :918
+
+    if (cf.russian_roul) {  // :923-933, q from the throughput BEFORE this bounce's factor
+        const float q = 1.0f - fminf(fmaxf(fmaxf(sg.thr.x, sg.thr.y), sg.thr.z), 1.0f);
+        if (rnd(st) < q) addon_throughput *= mk3(.0f);
+        else addon_throughput *= (1.0f / (1.0f - q));
+    }
+    sg.thr *= addon_throughput;  // :940
+    sg.o = at.P;                 // :954
+    sg.d = w_i;                  // :956
+    sg.depth++;                  // :959-962 (the condition there is a tautology)
+    return radiance;
+}
+
+template <int INTEG>
+__global__ __launch_bounds__(BLOCK) void k_shade(RenderParams rp, DevScene sc, PathState ps, const uint32_t* __restrict__ queue, uint32_t count,
+                                                 uint32_t npix_pad, uint32_t sample_begin, uint32_t* __restrict__ segctr,
+                                                 uint32_t* __restrict__ next_queue, uint32_t* __restrict__ next_count) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    bool alive = false;
+    uint32_t p = 0;
+    if (i < count) {
+        p = queue[i];
+        const float4 o4 = ps.o_seed[p], d4 = ps.d_depth[p], t4 = ps.thr[p];
+        Segment sg;
+        sg.o = mk3(o4.x, o4.y, o4.z);
+        sg.d = mk3(d4.x, d4.y, d4.z);
+        sg.thr = mk3(t4.x, t4.y, t4.z);
+        sg.seed = f2u(o4.w);
+        sg.depth = f2u(d4.w);
+        sg.done = false;
+        uint32_t bounce = f2u(t4.w);
+        const int ref = ps.hit_ref[p];
+        vec3 radiance;
+        if (ref == HIT_MISS) {  // Common.cu:13-18: background, NOT scaled by the throughput
+            radiance = mk3(rp.bg[0], rp.bg[1], rp.bg[2]);
+            sg.done = true;
+        } else {
+            HitAttr at;
+            hit_attributes(sc, ref, ps.hit_t[p], sg.o, sg.d, at);
+            if (INTEG == INT_RAYTRACER) radiance = shade_raytracer(rp, sc, ps, p, at, sg);
+            else if (INTEG == INT_ANALYTICDIRECT) radiance = shade_analytic(rp, sc, at, sg);
+            else if (INTEG == INT_DIRECT) radiance = shade_direct(rp, sc, ps, p, at, sg);
+            else if (INTEG == INT_PATHTRACER2) radiance = shade_pathtracer2(rp, sc, ps, p, at, sg);
+            else radiance = shade_pathtracer(rp, sc, ps, p, at, sg);
+        }
+        float4 L = ps.L[p];
+        L.x += radiance.x;  // PinholeCamera.cu:61
+        L.y += radiance.y;
+        L.z += radiance.z;
+        ps.L[p] = L;
+        ++bounce;
+        // PinholeCamera.cu:66 plus the segment cap and the zero-throughput cull
+        alive = !sg.done && sg.depth != rp.max_depth_eff && bounce < rp.bounce_cap;
+        if (alive && rp.cull_zero && sg.thr.x == 0.f && sg.thr.y == 0.f && sg.thr.z == 0.f) alive = false;
+        if (alive) {
+            const uint32_t pix = p % npix_pad;
+            uint32_t x, y;
+            pixel_of(rp, pix, x, y);
+            const uint32_t key0 = (x * rp.height + y) * rp.frame_id;
+            const uint32_t seed = segment_seed(rp, key0, sample_begin + p / npix_pad, bounce, segctr, pix);
+            ps.o_seed[p] = make_float4(sg.o.x, sg.o.y, sg.o.z, u2f(seed));
+            ps.d_depth[p] = make_float4(sg.d.x, sg.d.y, sg.d.z, u2f(sg.depth));
+            ps.thr[p] = make_float4(sg.thr.x, sg.thr.y, sg.thr.z, u2f(bounce));
+        }
+    }
+    queue_append(alive, p, next_queue, next_count);
+}
+
+// -------------------------------------------------------------- accumulate --
+__global__ __launch_bounds__(BLOCK) void k_accumulate(RenderParams rp, PathState ps, uint32_t npix_pad, uint32_t n_samples, float* __restrict__ acc, int replace) {
+    const uint32_t pix = blockIdx.x * BLOCK + threadIdx.x;
+    if (pix >= npix_pad) return;
+    uint32_t x, y;
+    if (!pixel_of(rp, pix, x, y)) return;
+    float* a = acc + 3 * ((size_t)y * rp.width + x);
+    if (replace) {  // the path started from the running sum, see k_generate
+        const float4 L = ps.L[pix];
+        a[0] = L.x; a[1] = L.y; a[2] = L.z;
+        return;
+    }
+    float r = a[0], g = a[1], b = a[2];
+    for (uint32_t s = 0; s < n_samples; ++s) {
+        const float4 L = ps.L[(size_t)s * npix_pad + pix];
+        r += L.x; g += L.y; b += L.z;
+    }
+    a[0] = r; a[1] = g; a[2] = b;
+}
+
+// ----------------------------------------------------------------- resolve --
+__global__ __launch_bounds__(BLOCK) void k_resolve(const float* __restrict__ acc, float* __restrict__ result, uint32_t n_pixels, int spp, float gamma, int frame_id) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n_pixels) return;
+    // PinholeCamera.cu:70-71
+    vec3 r = mk3(acc[3 * i], acc[3 * i + 1], acc[3 * i + 2]) / (float)spp;
+    r = mk3(powf(r.x, 1.0f / gamma), powf(r.y, 1.0f / gamma), powf(r.z, 1.0f / gamma));
+    if (frame_id != 1) {  // :75-80
+        const float u = 1.0f / (float)frame_id;
+        const vec3 old = mk3(result[3 * i], result[3 * i + 1], result[3 * i + 2]);
+        r = lerp3(old, r, u);
+    }
+    result[3 * i] = r.x;
+    result[3 * i + 1] = r.y;
+    result[3 * i + 2] = r.z;
+}
+
+// -------------------------------------------------------------- hit records --
+__global__ __launch_bounds__(BLOCK) void k_hit_records(RenderParams rp, DevScene sc, PathState ps, uint32_t npix_pad, PtcHitRecord* __restrict__ out) {
+    const uint32_t pix = blockIdx.x * BLOCK + threadIdx.x;
+    if (pix >= npix_pad) return;
+    uint32_t x, y;
+    if (!pixel_of(rp, pix, x, y)) return;
+    PtcHitRecord rec;
+    rec.prim = -1;
+    rec.t = rec.u = rec.v = 0.f;
+    const int ref = ps.hit_ref[pix];
+    if (ref != HIT_MISS) {
+        rec.t = ps.hit_t[pix];
+        if (ref >= 0) {
+            const float4 o4 = ps.o_seed[pix], d4 = ps.d_depth[pix];
+            const float4* q = sc.tri_q + 3 * (size_t)ref;
+            const Cand c = tri_candidate(q[0], q[1], q[2], mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z));
+            rec.u = c.u;
+            rec.v = c.v;
+            rec.prim = sc.tri_prim[ref];
+        } else {
+            rec.prim = sc.sph_prim[HIT_SPHERE_SLOT(ref)];
+        }
+    }
+    out[(size_t)y * rp.width + x] = rec;
+}
+
+// --------------------------------------------------------------- launchers --
+static inline uint32_t blocks_for(uint64_t n) { return (uint32_t)((n + BLOCK - 1) / BLOCK); }
+
+void wf_generate(hipStream_t s, const RenderParams& rp, const PathState& ps, uint32_t npix_pad, uint32_t n_paths, uint32_t sample_begin,
+                 const float* acc, uint32_t* segctr, int seed_L_from_acc, uint32_t* queue, uint32_t* qcount) {
+    hipLaunchKernelGGL(k_generate, dim3(blocks_for(n_paths)), dim3(BLOCK), 0, s, rp, ps, npix_pad, n_paths, sample_begin, acc, segctr, seed_L_from_acc, queue, qcount);
+}
+
+void wf_extend(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, uint32_t count, bool count_trav,
+               unsigned long long* trav_counters) {
+    if (count == 0) return;
+    if (count_trav)
+        hipLaunchKernelGGL(k_extend<true>, dim3(blocks_for(count)), dim3(BLOCK), 0, s, rp, sc, ps, queue, count, trav_counters);
+    else
+        hipLaunchKernelGGL(k_extend<false>, dim3(blocks_for(count)), dim3(BLOCK), 0, s, rp, sc, ps, queue, count, trav_counters);
+}
+
+template <int INTEG>
+static void launch_connect(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, uint32_t count,
+                           uint32_t n_samples, bool count_trav, unsigned long long* trav_counters, unsigned long long* shadow_counter) {
+    const uint64_t threads = (uint64_t)count * n_samples;
+    if (count_trav)
+        hipLaunchKernelGGL((k_connect<INTEG, true>), dim3(blocks_for(threads)), dim3(BLOCK), 0, s, rp, sc, ps, queue, count, n_samples, trav_counters, shadow_counter);
+    else
+        hipLaunchKernelGGL((k_connect<INTEG, false>), dim3(blocks_for(threads)), dim3(BLOCK), 0, s, rp, sc, ps, queue, count, n_samples, trav_counters, shadow_counter);
+}
+
+void wf_connect(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, uint32_t count, uint32_t n_samples,
+                bool count_trav, unsigned long long* trav_counters, unsigned long long* shadow_counter) {
+    if (count == 0 || n_samples == 0) return;
+    switch (rp.integrator) {
+        case INT_RAYTRACER: launch_connect<INT_RAYTRACER>(s, rp, sc, ps, queue, count, n_samples, count_trav, trav_counters, shadow_counter); break;
+        case INT_DIRECT: launch_connect<INT_DIRECT>(s, rp, sc, ps, queue, count, n_samples, count_trav, trav_counters, shadow_counter); break;
+        case INT_PATHTRACER: launch_connect<INT_PATHTRACER>(s, rp, sc, ps, queue, count, n_samples, count_trav, trav_counters, shadow_counter); break;
+        case INT_PATHTRACER2: launch_connect<INT_PATHTRACER2>(s, rp, sc, ps, queue, count, n_samples, count_trav, trav_counters, shadow_counter); break;
+        default: break;
+    }
+}
+
+void wf_shade(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, uint32_t count, uint32_t npix_pad,
+              uint32_t sample_begin, uint32_t* segctr, uint32_t* next_queue, uint32_t* next_count) {
+    if (count == 0) return;
+    const dim3 g(blocks_for(count)), b(BLOCK);
+    switch (rp.integrator) {
+        case INT_RAYTRACER: hipLaunchKernelGGL(k_shade<INT_RAYTRACER>, g, b, 0, s, rp, sc, ps, queue, count, npix_pad, sample_begin, segctr, next_queue, next_count); break;
+        case INT_ANALYTICDIRECT: hipLaunchKernelGGL(k_shade<INT_ANALYTICDIRECT>, g, b, 0, s, rp, sc, ps, queue, count, npix_pad, sample_begin, segctr, next_queue, next_count); break;
+        case INT_DIRECT: hipLaunchKernelGGL(k_shade<INT_DIRECT>, g, b, 0, s, rp, sc, ps, queue, count, npix_pad, sample_begin, segctr, next_queue, next_count); break;
+        case INT_PATHTRACER: hipLaunchKernelGGL(k_shade<INT_PATHTRACER>, g, b, 0, s, rp, sc, ps, queue, count, npix_pad, sample_begin, segctr, next_queue, next_count); break;
+        case INT_PATHTRACER2: hipLaunchKernelGGL(k_shade<INT_PATHTRACER2>, g, b, 0, s, rp, sc, ps, queue, count, npix_pad, sample_begin, segctr, next_queue, next_count); break;
+        default: break;
+    }
+}
+
+void wf_accumulate(hipStream_t s, const RenderParams& rp, const PathState& ps, uint32_t npix_pad, uint32_t n_samples, float* acc, int replace) {
+    hipLaunchKernelGGL(k_accumulate, dim3(blocks_for(npix_pad)), dim3(BLOCK), 0, s, rp, ps, npix_pad, n_samples, acc, replace);
+}
+
+void wf_resolve(hipStream_t s, const float* acc, float* result, uint32_t n_pixels, int spp, float gamma, int frame_id) {
+    hipLaunchKernelGGL(k_resolve, dim3(blocks_for(n_pixels)), dim3(BLOCK), 0, s, acc, result, n_pixels, spp, gamma, frame_id);
+}
+
+void wf_hit_records(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, uint32_t npix_pad, PtcHitRecord* out) {
+    hipLaunchKernelGGL(k_hit_records, dim3(blocks_for(npix_pad)), dim3(BLOCK), 0, s, rp, sc, ps, npix_pad, out);
+}

@@ -1,0 +1,73 @@
+"""Shared helpers for the tests."""
+import os
+import struct
+import zlib
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def scene_text(rel):
+    with open(os.path.join(ROOT, "scenes", rel)) as f:
+        return f.read()
+
+
+def read_png(path):
+    """Minimal PNG reader (8-bit RGB / RGBA, non-interlaced) -> uint8 (H, W, C)."""
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n", "not a PNG"
+    pos, idat, w = 8, b"", None
+    while pos < len(data):
+        n, typ = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        assert zlib.crc32(typ + body) & 0xFFFFFFFF == struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0], "bad chunk CRC"
+        if typ == b"IHDR":
+            w, h, depth, ctype, _, _, interlace = struct.unpack(">IIBBBBB", body)
+            assert depth == 8 and ctype in (2, 6) and interlace == 0
+            ch = 3 if ctype == 2 else 4
+        elif typ == b"IDAT":
+            idat += body
+        pos += 12 + n
+    raw = zlib.decompress(idat)
+    stride = w * ch
+    out = np.zeros((h, stride), dtype=np.uint8)
+    prev = np.zeros(stride, dtype=np.int32)
+    p = 0
+    for y in range(h):
+        f = raw[p]
+        line = np.frombuffer(raw, dtype=np.uint8, count=stride, offset=p + 1).astype(np.int32)
+        p += stride + 1
+        if f == 0:
+            cur = line
+        elif f == 2:
+            cur = (line + prev) & 255
+        else:
+            cur = np.zeros(stride, dtype=np.int32)
+            for i in range(stride):
+                a = cur[i - ch] if i >= ch else 0
+                b = prev[i]
+                c = prev[i - ch] if i >= ch else 0
+                if f == 1:
+                    pred = a
+                elif f == 3:
+                    pred = (a + b) >> 1
+                else:
+                    pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
+                    pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                cur[i] = (line[i] + pred) & 255
+        out[y] = cur
+        prev = cur
+    return out.reshape(h, w, ch)
+
+
+def block_mean(a, b=16):
+    h, w, c = a.shape
+    return a[:h // b * b, :w // b * b].reshape(h // b, b, w // b, b, c).mean(axis=(1, 3))
+
+
+def close_fraction(a, b, rtol=1e-3, atol=1e-3):
+    """Fraction of pixels whose channels all agree within atol + rtol*|b| (NaNs must match)."""
+    both_nan = np.isnan(a) & np.isnan(b)
+    ok = (np.abs(a - b) <= atol + rtol * np.abs(b)) | both_nan
+    return float(ok.all(axis=-1).mean())
