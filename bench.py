@@ -68,6 +68,7 @@ def main():
     import torch
     import torch.distributed as dist
     from pathtracer_amd import Renderer, _ffi
+    from pathtracer_amd.distributed import split_render_step
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -92,12 +93,8 @@ def main():
     r.set_stream(torch.cuda.current_stream().cuda_stream)
 
     def step():
-        # this rank's share of the global sample index space
-        r.render_range(rank * spp, (rank + 1) * spp, clear=True)
-        if world > 1:
-            dist.reduce(sums, dst=0, op=dist.ReduceOp.SUM)
-        if rank == 0:
-            r.resolve(world * spp)
+        # this rank's share of the global sample index space, then one RCCL reduce
+        split_render_step(r, sums, rank, world, spp, dist)
 
     def sync():
         torch.cuda.synchronize()
