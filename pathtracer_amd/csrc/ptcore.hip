@@ -68,9 +68,10 @@ struct ptc_context {
     // wavefront state
     PathState ps{};
     uint32_t contrib_samples = 0;
-    uint32_t* queue[2] = {nullptr, nullptr};
-    uint32_t* qcount = nullptr;                 // [2]
-    unsigned long long* counters = nullptr;     // [0..3] traversal, [4] shadow rays
+    uint32_t* queue[2] = {nullptr, nullptr};    // live paths of this / the next bounce
+    uint32_t* hitq = nullptr;                   // paths of this bounce that hit something
+    uint32_t* qcount = nullptr;                 // [0..3] two {hit, next} pairs used alternately, [4] generate
+    unsigned long long* counters = nullptr;     // [0..3] traversal, [16 + 16*k] shadow-ray shards
     uint32_t* h_count = nullptr;                // pinned
 
     // options
@@ -122,10 +123,10 @@ void freeTargets(ptc_context* c) {
 
 void freePaths(ptc_context* c) {
     for (void* p : {(void*)c->ps.o_seed, (void*)c->ps.d_depth, (void*)c->ps.thr, (void*)c->ps.L, (void*)c->ps.hit_t, (void*)c->ps.hit_ref,
-                    (void*)c->ps.contrib, (void*)c->queue[0], (void*)c->queue[1]})
+                    (void*)c->ps.contrib, (void*)c->queue[0], (void*)c->queue[1], (void*)c->hitq})
         if (p) (void)hipFree(p);
     c->ps = PathState{};
-    c->queue[0] = c->queue[1] = nullptr;
+    c->queue[0] = c->queue[1] = c->hitq = nullptr;
     c->contrib_samples = 0;
 }
 
@@ -167,6 +168,7 @@ int ensurePaths(ptc_context* ctx, uint32_t capacity, uint32_t contrib_samples) {
     CHK(hipMalloc((void**)&ctx->ps.contrib, std::max<size_t>((size_t)capacity * contrib_samples * 3, 1) * sizeof(float)));
     CHK(hipMalloc((void**)&ctx->queue[0], (size_t)capacity * sizeof(uint32_t)));
     CHK(hipMalloc((void**)&ctx->queue[1], (size_t)capacity * sizeof(uint32_t)));
+    CHK(hipMalloc((void**)&ctx->hitq, (size_t)capacity * sizeof(uint32_t)));
     ctx->ps.capacity = capacity;
     ctx->contrib_samples = contrib_samples;
     return PTC_OK;
@@ -282,34 +284,42 @@ int uploadLights(ptc_context* ctx) {
     return PTC_OK;
 }
 
-// Trace every bounce of the paths in queue[0] (count0 of them).
+#define N_COUNTERS (16 + 16 * WF_SHADOW_SHARDS)
+
+// Trace every bounce of the paths in queue[0] (count0 of them).  Per bounce:
+// extend (-> hit queue), connect and shade over the hit queue (its length stays on
+// the device; the grids are sized by the bounce's path count), survivors -> next
+// queue, whose length is the one word read back.
 int runBounces(ptc_context* ctx, const RenderParams& rp, const DevScene& sc, uint32_t count0, uint32_t sample_begin) {
     uint32_t count = count0;
     int cur = 0;
+    uint32_t bounce = 0;
     const uint32_t S = rp.samples_per_path;
     while (count > 0) {
+        uint32_t* pair = ctx->qcount + 2 * (bounce & 1u);  // {hit count, next count}
+        CHK(hipMemsetAsync(pair, 0, 2 * sizeof(uint32_t), ctx->stream));
         {
             Timed t(ctx, 0);
-            wf_extend(ctx->stream, rp, sc, ctx->ps, ctx->queue[cur], count, ctx->count_trav != 0, ctx->counters);
+            wf_extend(ctx->stream, rp, sc, ctx->ps, ctx->queue[cur], count, ctx->hitq, pair, ctx->count_trav != 0, ctx->counters);
         }
         ctx->stats.extension_rays += count;
         ctx->stats.extend_launches++;
         if (S) {
             Timed t(ctx, 1);
-            wf_connect(ctx->stream, rp, sc, ctx->ps, ctx->queue[cur], count, S, ctx->count_trav != 0, ctx->counters, ctx->counters + 4);
+            wf_connect(ctx->stream, rp, sc, ctx->ps, ctx->hitq, pair, count, S, ctx->count_trav != 0, ctx->counters, ctx->counters + 16);
             ctx->stats.connect_launches++;
         }
-        CHK(hipMemsetAsync(ctx->qcount + (cur ^ 1), 0, sizeof(uint32_t), ctx->stream));
         {
             Timed t(ctx, 2);
-            wf_shade(ctx->stream, rp, sc, ctx->ps, ctx->queue[cur], count, ctx->npix_pad, sample_begin, ctx->segctr, ctx->queue[cur ^ 1], ctx->qcount + (cur ^ 1));
+            wf_shade(ctx->stream, rp, sc, ctx->ps, ctx->hitq, pair, count, ctx->npix_pad, sample_begin, ctx->segctr, ctx->queue[cur ^ 1], pair + 1);
         }
         ctx->stats.shade_launches++;
-        CHK(hipMemcpyAsync(ctx->h_count, ctx->qcount + (cur ^ 1), sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        CHK(hipMemcpyAsync(ctx->h_count, pair + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         CHK(hipStreamSynchronize(ctx->stream));
         CHK(hipGetLastError());
         count = *ctx->h_count;
         cur ^= 1;
+        ++bounce;
     }
     return PTC_OK;
 }
@@ -347,12 +357,12 @@ int renderRange(ptc_context* ctx, int frame_id, uint32_t w, uint32_t h, int32_t 
         const uint32_t ns = (uint32_t)std::min<int64_t>((int64_t)per_batch, j1 - ja);
         const uint32_t n_paths = ns * ctx->npix_pad;
         const int seedL = rp.seeding == 0 ? 1 : 0;  // reference order: result += radiance per segment
-        CHK(hipMemsetAsync(ctx->qcount, 0, 2 * sizeof(uint32_t), ctx->stream));
+        CHK(hipMemsetAsync(ctx->qcount + 4, 0, sizeof(uint32_t), ctx->stream));
         {
             Timed t(ctx, 3);
-            wf_generate(ctx->stream, rp, ctx->ps, ctx->npix_pad, n_paths, (uint32_t)ja, ctx->acc, ctx->segctr, seedL, ctx->queue[0], ctx->qcount);
+            wf_generate(ctx->stream, rp, ctx->ps, ctx->npix_pad, n_paths, (uint32_t)ja, ctx->acc, ctx->segctr, seedL, ctx->queue[0], ctx->qcount + 4);
         }
-        CHK(hipMemcpyAsync(ctx->h_count, ctx->qcount, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        CHK(hipMemcpyAsync(ctx->h_count, ctx->qcount + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         CHK(hipStreamSynchronize(ctx->stream));
         const uint32_t count0 = *ctx->h_count;
         ctx->stats.paths += count0;
@@ -417,9 +427,9 @@ int ptc_create(int device_ordinal, ptc_context** out) {
     };
     if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     ctx->stream = ctx->own_stream;
-    if ((e = hipMalloc((void**)&ctx->qcount, 2 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
-    if ((e = hipMalloc((void**)&ctx->counters, 8 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
-    if ((e = hipMemset(ctx->counters, 0, 8 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
+    if ((e = hipMalloc((void**)&ctx->qcount, 8 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc((void**)&ctx->counters, N_COUNTERS * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMemset(ctx->counters, 0, N_COUNTERS * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
     if ((e = hipHostMalloc((void**)&ctx->h_count, sizeof(uint32_t))) != hipSuccess) return bail("hipHostMalloc", e);
     *out = ctx;
     return PTC_OK;
@@ -616,12 +626,12 @@ int ptc_primary_hits(ptc_context* ctx, uint32_t width, uint32_t height, PtcHitRe
     rc = ensurePaths(ctx, ctx->npix_pad, 0);
     if (rc) return rc;
     const DevScene sc = deviceScene(ctx);
-    CHK(hipMemsetAsync(ctx->qcount, 0, 2 * sizeof(uint32_t), ctx->stream));
+    CHK(hipMemsetAsync(ctx->qcount, 0, 8 * sizeof(uint32_t), ctx->stream));
     CHK(hipMemsetAsync(ctx->ps.hit_ref, 0xFF, (size_t)ctx->npix_pad * sizeof(int32_t), ctx->stream));  // HIT_MISS
-    wf_generate(ctx->stream, rp, ctx->ps, ctx->npix_pad, ctx->npix_pad, 0u, ctx->acc, ctx->segctr, 0, ctx->queue[0], ctx->qcount);
-    CHK(hipMemcpyAsync(ctx->h_count, ctx->qcount, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    wf_generate(ctx->stream, rp, ctx->ps, ctx->npix_pad, ctx->npix_pad, 0u, ctx->acc, ctx->segctr, 0, ctx->queue[0], ctx->qcount + 4);
+    CHK(hipMemcpyAsync(ctx->h_count, ctx->qcount + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     CHK(hipStreamSynchronize(ctx->stream));
-    wf_extend(ctx->stream, rp, sc, ctx->ps, ctx->queue[0], *ctx->h_count, false, ctx->counters);
+    wf_extend(ctx->stream, rp, sc, ctx->ps, ctx->queue[0], *ctx->h_count, ctx->hitq, ctx->qcount, false, ctx->counters);
     wf_hit_records(ctx->stream, rp, sc, ctx->ps, ctx->npix_pad, ctx->d_hits);
     CHK(hipMemcpyAsync(out, ctx->d_hits, (size_t)width * height * sizeof(PtcHitRecord), hipMemcpyDeviceToHost, ctx->stream));
     CHK(hipStreamSynchronize(ctx->stream));
@@ -701,13 +711,14 @@ int ptc_get_stats(ptc_context* ctx, PtcStats* out) {
     if (!out) return fail(ctx, PTC_ERR_INVALID, "null output");
     CHK(hipStreamSynchronize(ctx->stream));
     collectSpans(ctx);
-    unsigned long long h[8];
-    CHK(hipMemcpy(h, ctx->counters, sizeof(h), hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> h(N_COUNTERS);
+    CHK(hipMemcpy(h.data(), ctx->counters, N_COUNTERS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     ctx->stats.nodes_visited = h[0];
     ctx->stats.prims_tested = h[1];
     ctx->stats.shadow_nodes_visited = h[2];
     ctx->stats.shadow_prims_tested = h[3];
-    ctx->stats.shadow_rays = h[4];
+    ctx->stats.shadow_rays = 0;
+    for (int k = 0; k < WF_SHADOW_SHARDS; ++k) ctx->stats.shadow_rays += h[16 + 16 * k];
     *out = ctx->stats;
     return PTC_OK;
 }
@@ -716,7 +727,7 @@ int ptc_reset_stats(ptc_context* ctx) {
     ENTER();
     CHK(hipStreamSynchronize(ctx->stream));
     collectSpans(ctx);
-    CHK(hipMemset(ctx->counters, 0, 8 * sizeof(unsigned long long)));
+    CHK(hipMemset(ctx->counters, 0, N_COUNTERS * sizeof(unsigned long long)));
     const double build_ms = ctx->stats.build_ms;
     const uint32_t nodes = ctx->stats.bvh_nodes, depth = ctx->stats.bvh_max_depth;
     ctx->stats = PtcStats{};

@@ -24,6 +24,8 @@
 #include "wavefront.h"
 
 #define BLOCK TRAV_BLOCK
+#define GEN_BLOCK 1024   /* generate / shade: one queue atomic per 1024 paths */
+#define SHADOW_SHARDS 64  /* shadow-ray counter words, 128 B apart */
 
 // ---------------------------------------------------------------- helpers --
 
@@ -40,17 +42,28 @@ __device__ __forceinline__ bool pixel_of(const RenderParams& rp, uint32_t pix, u
     return x < rp.width && y < rp.height;
 }
 
-// Append `value` for every lane with keep=true; one atomic per wave.  Must be
-// reached by all lanes of the wave that are still running.
+// Append `value` for every thread with keep=true.  Wave64 ballot + popcount give
+// the position inside the wave, the waves' counts meet in LDS and ONE atomic per
+// block reserves the block's span (a per-wave atomic on the single counter word
+// saturates the atomic unit at these queue sizes).  Must be reached by every
+// thread of the block.
 __device__ __forceinline__ void queue_append(bool keep, uint32_t value, uint32_t* __restrict__ out, uint32_t* __restrict__ counter) {
+    __shared__ uint32_t s_cnt[16];
+    __shared__ uint32_t s_base;
     const unsigned long long mask = __ballot(keep);
-    if (mask == 0ull) return;
     const uint32_t lane = __lane_id();
+    const uint32_t wave = threadIdx.x >> 6, nwaves = (blockDim.x + 63u) >> 6;
     const uint32_t prefix = __popcll(mask & ((1ull << lane) - 1ull));
-    const int leader = __ffsll((long long)mask) - 1;
-    uint32_t base = 0;
-    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-    base = __shfl(base, leader);
+    if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < nwaves; ++w) total += s_cnt[w];
+        s_base = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t base = s_base;
+    for (uint32_t w = 0; w < wave; ++w) base += s_cnt[w];
     if (keep) out[base + prefix] = value;
 }
 
@@ -64,10 +77,10 @@ __device__ __forceinline__ uint32_t segment_seed(const RenderParams& rp, uint32_
 }
 
 // ---------------------------------------------------------------- generate --
-__global__ __launch_bounds__(BLOCK) void k_generate(RenderParams rp, PathState ps, uint32_t npix_pad, uint32_t n_paths, uint32_t sample_begin,
+__global__ __launch_bounds__(GEN_BLOCK) void k_generate(RenderParams rp, PathState ps, uint32_t npix_pad, uint32_t n_paths, uint32_t sample_begin,
                                                     const float* __restrict__ acc, uint32_t* __restrict__ segctr, int seed_L_from_acc,
                                                     uint32_t* __restrict__ queue, uint32_t* __restrict__ qcount) {
-    const uint32_t p = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t p = blockIdx.x * GEN_BLOCK + threadIdx.x;
     bool valid = p < n_paths;
     uint32_t x = 0, y = 0, pix = 0, j = 0;
     if (valid) {
@@ -104,27 +117,44 @@ __global__ __launch_bounds__(BLOCK) void k_generate(RenderParams rp, PathState p
 }
 
 // ------------------------------------------------------------------ extend --
+// Closest hit of every queued path.  Paths that hit something are appended to
+// `hit_queue` (the only ones the connect and shade kernels need to look at); a
+// miss ends the path right here: radiance = background colour, not scaled by the
+// throughput (Common.cu:13-18).
 template <bool COUNT>
 __global__ __launch_bounds__(BLOCK) void k_extend(RenderParams rp, DevScene sc, PathState ps, const uint32_t* __restrict__ queue, uint32_t count,
+                                                  uint32_t* __restrict__ hit_queue, uint32_t* __restrict__ hit_count,
                                                   unsigned long long* __restrict__ trav_counters) {
     __shared__ uint32_t stack[TRAV_LDS_STACK * BLOCK];
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= count) return;
-    const uint32_t p = queue[i];
-    const float4 o4 = ps.o_seed[p], d4 = ps.d_depth[p];
-    const vec3 o = mk3(o4.x, o4.y, o4.z), d = mk3(d4.x, d4.y, d4.z);
-    ClosestHit best;
-    TravCounters cnt = {0u, 0u};
-    if (rp.brute_force)
-        brute_force<false>(sc, o, d, rp.cf.epsilon, PT_RAY_MAX, best);
-    else
-        traverse<false, COUNT>(sc, o, d, rp.cf.epsilon, PT_RAY_MAX, stack + threadIdx.x, best, cnt);
-    ps.hit_t[p] = best.t;
-    ps.hit_ref[p] = best.ref;
-    if (COUNT) {
-        atomicAdd(&trav_counters[0], (unsigned long long)cnt.nodes);
-        atomicAdd(&trav_counters[1], (unsigned long long)cnt.prims);
+    bool hit = false;
+    uint32_t p = 0;
+    if (i < count) {
+        p = queue[i];
+        const float4 o4 = ps.o_seed[p], d4 = ps.d_depth[p];
+        const vec3 o = mk3(o4.x, o4.y, o4.z), d = mk3(d4.x, d4.y, d4.z);
+        ClosestHit best;
+        TravCounters cnt = {0u, 0u};
+        if (rp.brute_force)
+            brute_force<false>(sc, o, d, rp.cf.epsilon, PT_RAY_MAX, best);
+        else
+            traverse<false, COUNT>(sc, o, d, rp.cf.epsilon, PT_RAY_MAX, stack + threadIdx.x, best, cnt);
+        ps.hit_t[p] = best.t;
+        ps.hit_ref[p] = best.ref;
+        hit = best.ref != HIT_MISS;
+        if (!hit && (rp.bg[0] != 0.f || rp.bg[1] != 0.f || rp.bg[2] != 0.f)) {
+            float4 L = ps.L[p];
+            L.x += rp.bg[0];
+            L.y += rp.bg[1];
+            L.z += rp.bg[2];
+            ps.L[p] = L;
+        }
+        if (COUNT) {
+            atomicAdd(&trav_counters[0], (unsigned long long)cnt.nodes);
+            atomicAdd(&trav_counters[1], (unsigned long long)cnt.prims);
+        }
     }
+    queue_append(hit, p, hit_queue, hit_count);
 }
 
 // ----------------------------------------------------------------- connect --
@@ -133,10 +163,11 @@ __device__ __forceinline__ const PtcMaterialValue& material_of(const DevScene& s
 __device__ __forceinline__ bool is_light(uint32_t mat) { return (mat & MAT_LIGHT_BIT) != 0u; }
 
 template <int INTEG, bool COUNT>
-__global__ __launch_bounds__(BLOCK) void k_connect(RenderParams rp, DevScene sc, PathState ps, const uint32_t* __restrict__ queue, uint32_t count,
-                                                   uint32_t n_samples, unsigned long long* __restrict__ trav_counters,
-                                                   unsigned long long* __restrict__ shadow_counter) {
+__global__ __launch_bounds__(BLOCK) void k_connect(RenderParams rp, DevScene sc, PathState ps, const uint32_t* __restrict__ queue,
+                                                   const uint32_t* __restrict__ count_ptr, uint32_t n_samples,
+                                                   unsigned long long* __restrict__ trav_counters, unsigned long long* __restrict__ shadow_counter) {
     __shared__ uint32_t stack[TRAV_LDS_STACK * BLOCK];
+    const uint32_t count = *count_ptr;  // hits of this bounce, written by k_extend
     const uint64_t tid = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (tid >= (uint64_t)count * n_samples) return;
     const uint32_t i = (uint32_t)(tid % count), q = (uint32_t)(tid / count);
@@ -271,9 +302,10 @@ __global__ __launch_bounds__(BLOCK) void k_connect(RenderParams rp, DevScene sc,
     out[0] = term.x;
     out[ps.capacity] = term.y;
     out[2u * (size_t)ps.capacity] = term.z;
-    // one atomic per wave for the shadow-ray count
+    // shadow-ray count: one atomic per wave, spread over SHADOW_SHARDS words
     const unsigned long long m = __ballot(traced);
-    if (m && __lane_id() == (uint32_t)(__ffsll((long long)m) - 1)) atomicAdd(shadow_counter, (unsigned long long)__popcll(m));
+    if (m && __lane_id() == (uint32_t)(__ffsll((long long)m) - 1))
+        atomicAdd(shadow_counter + 16u * (blockIdx.x % SHADOW_SHARDS), (unsigned long long)__popcll(m));
 }
 
 // ------------------------------------------------------------------- shade --
@@ -529,10 +561,11 @@ __device__ __forceinline__ vec3 shade_pathtracer(const RenderParams& rp, const D
 }
 
 template <int INTEG>
-__global__ __launch_bounds__(BLOCK) void k_shade(RenderParams rp, DevScene sc, PathState ps, const uint32_t* __restrict__ queue, uint32_t count,
-                                                 uint32_t npix_pad, uint32_t sample_begin, uint32_t* __restrict__ segctr,
-                                                 uint32_t* __restrict__ next_queue, uint32_t* __restrict__ next_count) {
-    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+__global__ __launch_bounds__(GEN_BLOCK) void k_shade(RenderParams rp, DevScene sc, PathState ps, const uint32_t* __restrict__ queue,
+                                                     const uint32_t* __restrict__ count_ptr, uint32_t npix_pad, uint32_t sample_begin,
+                                                     uint32_t* __restrict__ segctr, uint32_t* __restrict__ next_queue, uint32_t* __restrict__ next_count) {
+    const uint32_t count = *count_ptr;  // hits of this bounce, written by k_extend
+    const uint32_t i = blockIdx.x * GEN_BLOCK + threadIdx.x;
     bool alive = false;
     uint32_t p = 0;
     if (i < count) {
@@ -548,18 +581,13 @@ __global__ __launch_bounds__(BLOCK) void k_shade(RenderParams rp, DevScene sc, P
         uint32_t bounce = f2u(t4.w);
         const int ref = ps.hit_ref[p];
         vec3 radiance;
-        if (ref == HIT_MISS) {  // Common.cu:13-18: background, NOT scaled by the throughput
-            radiance = mk3(rp.bg[0], rp.bg[1], rp.bg[2]);
-            sg.done = true;
-        } else {
-            HitAttr at;
-            hit_attributes(sc, ref, ps.hit_t[p], sg.o, sg.d, at);
-            if (INTEG == INT_RAYTRACER) radiance = shade_raytracer(rp, sc, ps, p, at, sg);
-            else if (INTEG == INT_ANALYTICDIRECT) radiance = shade_analytic(rp, sc, at, sg);
-            else if (INTEG == INT_DIRECT) radiance = shade_direct(rp, sc, ps, p, at, sg);
-            else if (INTEG == INT_PATHTRACER2) radiance = shade_pathtracer2(rp, sc, ps, p, at, sg);
-            else radiance = shade_pathtracer(rp, sc, ps, p, at, sg);
-        }
+        HitAttr at;  // only paths with a hit are queued here
+        hit_attributes(sc, ref, ps.hit_t[p], sg.o, sg.d, at);
+        if (INTEG == INT_RAYTRACER) radiance = shade_raytracer(rp, sc, ps, p, at, sg);
+        else if (INTEG == INT_ANALYTICDIRECT) radiance = shade_analytic(rp, sc, at, sg);
+        else if (INTEG == INT_DIRECT) radiance = shade_direct(rp, sc, ps, p, at, sg);
+        else if (INTEG == INT_PATHTRACER2) radiance = shade_pathtracer2(rp, sc, ps, p, at, sg);
+        else radiance = shade_pathtracer(rp, sc, ps, p, at, sg);
         float4 L = ps.L[p];
         L.x += radiance.x;  // PinholeCamera.cu:61
         L.y += radiance.y;
@@ -647,54 +675,56 @@ __global__ __launch_bounds__(BLOCK) void k_hit_records(RenderParams rp, DevScene
 }
 
 // --------------------------------------------------------------- launchers --
-static inline uint32_t blocks_for(uint64_t n) { return (uint32_t)((n + BLOCK - 1) / BLOCK); }
+static inline uint32_t blocks_for(uint64_t n, uint32_t block = BLOCK) { return (uint32_t)((n + block - 1) / block); }
 
 void wf_generate(hipStream_t s, const RenderParams& rp, const PathState& ps, uint32_t npix_pad, uint32_t n_paths, uint32_t sample_begin,
                  const float* acc, uint32_t* segctr, int seed_L_from_acc, uint32_t* queue, uint32_t* qcount) {
-    hipLaunchKernelGGL(k_generate, dim3(blocks_for(n_paths)), dim3(BLOCK), 0, s, rp, ps, npix_pad, n_paths, sample_begin, acc, segctr, seed_L_from_acc, queue, qcount);
+    hipLaunchKernelGGL(k_generate, dim3(blocks_for(n_paths, GEN_BLOCK)), dim3(GEN_BLOCK), 0, s, rp, ps, npix_pad, n_paths, sample_begin, acc, segctr,
+                       seed_L_from_acc, queue, qcount);
 }
 
-void wf_extend(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, uint32_t count, bool count_trav,
-               unsigned long long* trav_counters) {
+void wf_extend(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, uint32_t count, uint32_t* hit_queue,
+               uint32_t* hit_count, bool count_trav, unsigned long long* trav_counters) {
     if (count == 0) return;
     if (count_trav)
-        hipLaunchKernelGGL(k_extend<true>, dim3(blocks_for(count)), dim3(BLOCK), 0, s, rp, sc, ps, queue, count, trav_counters);
+        hipLaunchKernelGGL(k_extend<true>, dim3(blocks_for(count)), dim3(BLOCK), 0, s, rp, sc, ps, queue, count, hit_queue, hit_count, trav_counters);
     else
-        hipLaunchKernelGGL(k_extend<false>, dim3(blocks_for(count)), dim3(BLOCK), 0, s, rp, sc, ps, queue, count, trav_counters);
+        hipLaunchKernelGGL(k_extend<false>, dim3(blocks_for(count)), dim3(BLOCK), 0, s, rp, sc, ps, queue, count, hit_queue, hit_count, trav_counters);
 }
 
 template <int INTEG>
-static void launch_connect(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, uint32_t count,
-                           uint32_t n_samples, bool count_trav, unsigned long long* trav_counters, unsigned long long* shadow_counter) {
-    const uint64_t threads = (uint64_t)count * n_samples;
+static void launch_connect(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, const uint32_t* count_ptr,
+                           uint32_t max_count, uint32_t n_samples, bool count_trav, unsigned long long* trav_counters, unsigned long long* shadow_counter) {
+    const uint64_t threads = (uint64_t)max_count * n_samples;
     if (count_trav)
-        hipLaunchKernelGGL((k_connect<INTEG, true>), dim3(blocks_for(threads)), dim3(BLOCK), 0, s, rp, sc, ps, queue, count, n_samples, trav_counters, shadow_counter);
+        hipLaunchKernelGGL((k_connect<INTEG, true>), dim3(blocks_for(threads)), dim3(BLOCK), 0, s, rp, sc, ps, queue, count_ptr, n_samples, trav_counters, shadow_counter);
     else
-        hipLaunchKernelGGL((k_connect<INTEG, false>), dim3(blocks_for(threads)), dim3(BLOCK), 0, s, rp, sc, ps, queue, count, n_samples, trav_counters, shadow_counter);
+        hipLaunchKernelGGL((k_connect<INTEG, false>), dim3(blocks_for(threads)), dim3(BLOCK), 0, s, rp, sc, ps, queue, count_ptr, n_samples, trav_counters, shadow_counter);
 }
 
-void wf_connect(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, uint32_t count, uint32_t n_samples,
-                bool count_trav, unsigned long long* trav_counters, unsigned long long* shadow_counter) {
-    if (count == 0 || n_samples == 0) return;
+// `count_ptr` (device) holds the number of queued paths; `max_count` bounds it and sizes the grid.
+void wf_connect(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, const uint32_t* count_ptr,
+                uint32_t max_count, uint32_t n_samples, bool count_trav, unsigned long long* trav_counters, unsigned long long* shadow_counter) {
+    if (max_count == 0 || n_samples == 0) return;
     switch (rp.integrator) {
-        case INT_RAYTRACER: launch_connect<INT_RAYTRACER>(s, rp, sc, ps, queue, count, n_samples, count_trav, trav_counters, shadow_counter); break;
-        case INT_DIRECT: launch_connect<INT_DIRECT>(s, rp, sc, ps, queue, count, n_samples, count_trav, trav_counters, shadow_counter); break;
-        case INT_PATHTRACER: launch_connect<INT_PATHTRACER>(s, rp, sc, ps, queue, count, n_samples, count_trav, trav_counters, shadow_counter); break;
-        case INT_PATHTRACER2: launch_connect<INT_PATHTRACER2>(s, rp, sc, ps, queue, count, n_samples, count_trav, trav_counters, shadow_counter); break;
+        case INT_RAYTRACER: launch_connect<INT_RAYTRACER>(s, rp, sc, ps, queue, count_ptr, max_count, n_samples, count_trav, trav_counters, shadow_counter); break;
+        case INT_DIRECT: launch_connect<INT_DIRECT>(s, rp, sc, ps, queue, count_ptr, max_count, n_samples, count_trav, trav_counters, shadow_counter); break;
+        case INT_PATHTRACER: launch_connect<INT_PATHTRACER>(s, rp, sc, ps, queue, count_ptr, max_count, n_samples, count_trav, trav_counters, shadow_counter); break;
+        case INT_PATHTRACER2: launch_connect<INT_PATHTRACER2>(s, rp, sc, ps, queue, count_ptr, max_count, n_samples, count_trav, trav_counters, shadow_counter); break;
         default: break;
     }
 }
 
-void wf_shade(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, uint32_t count, uint32_t npix_pad,
-              uint32_t sample_begin, uint32_t* segctr, uint32_t* next_queue, uint32_t* next_count) {
-    if (count == 0) return;
-    const dim3 g(blocks_for(count)), b(BLOCK);
+void wf_shade(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, const uint32_t* count_ptr,
+              uint32_t max_count, uint32_t npix_pad, uint32_t sample_begin, uint32_t* segctr, uint32_t* next_queue, uint32_t* next_count) {
+    if (max_count == 0) return;
+    const dim3 g(blocks_for(max_count, GEN_BLOCK)), b(GEN_BLOCK);
     switch (rp.integrator) {
-        case INT_RAYTRACER: hipLaunchKernelGGL(k_shade<INT_RAYTRACER>, g, b, 0, s, rp, sc, ps, queue, count, npix_pad, sample_begin, segctr, next_queue, next_count); break;
-        case INT_ANALYTICDIRECT: hipLaunchKernelGGL(k_shade<INT_ANALYTICDIRECT>, g, b, 0, s, rp, sc, ps, queue, count, npix_pad, sample_begin, segctr, next_queue, next_count); break;
-        case INT_DIRECT: hipLaunchKernelGGL(k_shade<INT_DIRECT>, g, b, 0, s, rp, sc, ps, queue, count, npix_pad, sample_begin, segctr, next_queue, next_count); break;
-        case INT_PATHTRACER: hipLaunchKernelGGL(k_shade<INT_PATHTRACER>, g, b, 0, s, rp, sc, ps, queue, count, npix_pad, sample_begin, segctr, next_queue, next_count); break;
-        case INT_PATHTRACER2: hipLaunchKernelGGL(k_shade<INT_PATHTRACER2>, g, b, 0, s, rp, sc, ps, queue, count, npix_pad, sample_begin, segctr, next_queue, next_count); break;
+        case INT_RAYTRACER: hipLaunchKernelGGL(k_shade<INT_RAYTRACER>, g, b, 0, s, rp, sc, ps, queue, count_ptr, npix_pad, sample_begin, segctr, next_queue, next_count); break;
+        case INT_ANALYTICDIRECT: hipLaunchKernelGGL(k_shade<INT_ANALYTICDIRECT>, g, b, 0, s, rp, sc, ps, queue, count_ptr, npix_pad, sample_begin, segctr, next_queue, next_count); break;
+        case INT_DIRECT: hipLaunchKernelGGL(k_shade<INT_DIRECT>, g, b, 0, s, rp, sc, ps, queue, count_ptr, npix_pad, sample_begin, segctr, next_queue, next_count); break;
+        case INT_PATHTRACER: hipLaunchKernelGGL(k_shade<INT_PATHTRACER>, g, b, 0, s, rp, sc, ps, queue, count_ptr, npix_pad, sample_begin, segctr, next_queue, next_count); break;
+        case INT_PATHTRACER2: hipLaunchKernelGGL(k_shade<INT_PATHTRACER2>, g, b, 0, s, rp, sc, ps, queue, count_ptr, npix_pad, sample_begin, segctr, next_queue, next_count); break;
         default: break;
     }
 }
