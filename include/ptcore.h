@@ -151,7 +151,14 @@ enum {
     /* 1 = count BVH nodes visited / primitives tested per ray (slower). */
     PTC_OPT_COUNT_TRAVERSAL = 7,
     /* 0 = BVH traversal, 1 = brute force over all primitives (parity aid). */
-    PTC_OPT_BRUTE_FORCE = 8
+    PTC_OPT_BRUTE_FORCE = 8,
+    /* Traversal scheduling knobs for experiments: bits 0..7 idle lanes of a wave that
+     * trigger a refill (1..64); bits 8..11 extension rays, bits 12..15 shadow rays:
+     * 0 = one ray per thread, 1 = refilling waves + while-while rounds, 2 = refilling
+     * waves + single steps, 3 (shadow only) = 1 for trees of more than 256 nodes else 0;
+     * bits 16..31 queue entries a wave reserves per atomic (multiple of 64, 0 = auto).
+     * Default 0x3010. */
+    PTC_OPT_TUNE_TRAVERSAL = 9
 };
 
 /* ----------------------------------------------------------- entry points -- */

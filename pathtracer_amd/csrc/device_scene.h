@@ -102,6 +102,9 @@ struct RenderParams {
     int32_t brute_force;
     uint32_t samples_per_path;  // shadow-ray samples per segment (integrator dependent)
     uint32_t root_light_samples;
+    // traversal tuning: idle lanes that trigger a refill, 0 = one ray per thread, 1 = refilling waves + while-while rounds, 2 = refilling waves + single steps,
+    // entries a wave reserves per atomic (0 = chosen from the launch size)
+    uint32_t tune_refill, tune_mode, tune_shadow, tune_chunk;
 };
 
 // Per-path state, structure of arrays, `capacity` entries each.
@@ -112,6 +115,8 @@ struct PathState {
     float4* L;         // radiance accumulated by this path
     float* hit_t;      // closest-hit distance of the current segment
     int32_t* hit_ref;  // see HIT_*
-    float* contrib;    // [sample][capacity][3 planes]: per-shadow-sample f*G terms
+    float* contrib;    // 3 planes of [light sample][capacity]: per-shadow-sample f*G terms
+    float4* sh_o;      // queued shadow rays: origin.xyz, tmax
+    float4* sh_d;      // direction.xyz, index of the ray's term in `contrib` (bits)
     uint32_t capacity;
 };

@@ -186,16 +186,149 @@ __device__ __forceinline__ bool any_sphere(const DevScene& sc, uint32_t slot, ve
 
 __device__ __forceinline__ bool dir_is_nan(vec3 d) { return (d.x != d.x) || (d.y != d.y) || (d.z != d.z); }
 
-// One traversal routine for both ray types.
+// ---- traversal, written as resumable rounds ---------------------------------
+// A ray's traversal state is (cur, sp, stack); one ROUND descends through
+// internal nodes until a leaf is reached (or the stack runs dry) and then tests
+// that leaf's primitives.  The kernels call rounds in a loop and may hand a
+// finished lane a new ray between rounds, so that the lanes of a wave spend
+// their time in the same one of the two phases ("while-while" schedule).
 //   ANY = false: closest hit into `best` (rtTrace, ray type 0)
-//   ANY = true : returns true as soon as one primitive is accepted (ray type 1,
-//                the any-hit program of Common.cu:30-36 terminates the ray)
+//   ANY = true : stops at the first accepted primitive (ray type 1: the any-hit
+//                program of Common.cu:30-36 terminates the ray)
 // `lds_stack` points at this thread's column of a [TRAV_LDS_STACK][TRAV_BLOCK]
-// LDS array (entry i at lds_stack[i*TRAV_BLOCK]).
+// LDS array (entry i at lds_stack[i*TRAV_BLOCK]); deeper entries go to `spill`.
+struct TravRay {
+    vec3 o, d;
+    float ix, iy, iz;  // 1/d
+    float tmin, tmax;
+};
+
+#define REF_DONE REF_EMPTY_WORD
+
+__device__ __forceinline__ void trav_push(uint32_t* lds_stack, uint32_t* spill, int& sp, uint32_t v) {
+    if (sp < TRAV_LDS_STACK) lds_stack[sp * TRAV_BLOCK] = v;
+    else spill[sp - TRAV_LDS_STACK] = v;
+    ++sp;
+}
+
+__device__ __forceinline__ uint32_t trav_pop(const uint32_t* lds_stack, const uint32_t* spill, int& sp) {
+    if (sp == 0) return REF_DONE;
+    --sp;
+    return sp < TRAV_LDS_STACK ? lds_stack[sp * TRAV_BLOCK] : spill[sp - TRAV_LDS_STACK];
+}
+
 // A ray whose direction has a NaN component can never be accepted by either
-// primitive test (every comparison on t fails), so it is a miss up front.
+// primitive test (every comparison on t fails): it is a miss without traversal.
+__device__ __forceinline__ bool trav_init(const DevScene& sc, vec3 o, vec3 d, float tmin, float tmax, TravRay& r, int& sp, uint32_t& cur, ClosestHit& best) {
+    r.o = o;
+    r.d = d;
+    r.ix = 1.0f / d.x;
+    r.iy = 1.0f / d.y;
+    r.iz = 1.0f / d.z;
+    r.tmin = tmin;
+    r.tmax = tmax;
+    best.t = tmax;
+    best.ref = HIT_MISS;
+    best.prim = -1;
+    sp = 0;
+    cur = 0;  // internal node 0 = root
+    return !(dir_is_nan(d) || sc.n_nodes == 0);
+}
+
+// Visit one internal node: slab-test both child boxes against [tmin, lim], go to
+// the nearer hit child, push the farther one.
+template <bool COUNT>
+__device__ __forceinline__ uint32_t trav_node(const DevScene& sc, const TravRay& r, uint32_t cur, float lim, uint32_t* lds_stack, uint32_t* spill, int& sp,
+                                              TravCounters& cnt) {
+    const float4* n4 = reinterpret_cast<const float4*>(sc.nodes + REF_NODE(cur));
+    const float4 a = n4[0], b = n4[1], c = n4[2];
+    const uint4 ch = *reinterpret_cast<const uint4*>(n4 + 3);
+    if (COUNT) cnt.nodes++;
+    // child 0: lo=(a.x,a.y,a.z) hi=(a.w,b.x,b.y)
+    float t0 = (a.x - r.o.x) * r.ix, t1 = (a.w - r.o.x) * r.ix;
+    float n0 = fminf(t0, t1), f0 = fmaxf(t0, t1);
+    t0 = (a.y - r.o.y) * r.iy; t1 = (b.x - r.o.y) * r.iy;
+    n0 = fmaxf(n0, fminf(t0, t1)); f0 = fminf(f0, fmaxf(t0, t1));
+    t0 = (a.z - r.o.z) * r.iz; t1 = (b.y - r.o.z) * r.iz;
+    n0 = fmaxf(n0, fminf(t0, t1)); f0 = fminf(f0, fmaxf(t0, t1));
+    n0 = fmaxf(n0, r.tmin); f0 = fminf(f0, lim);
+    // child 1: lo=(b.z,b.w,c.x) hi=(c.y,c.z,c.w)
+    t0 = (b.z - r.o.x) * r.ix; t1 = (c.y - r.o.x) * r.ix;
+    float n1 = fminf(t0, t1), f1 = fmaxf(t0, t1);
+    t0 = (b.w - r.o.y) * r.iy; t1 = (c.z - r.o.y) * r.iy;
+    n1 = fmaxf(n1, fminf(t0, t1)); f1 = fminf(f1, fmaxf(t0, t1));
+    t0 = (c.x - r.o.z) * r.iz; t1 = (c.w - r.o.z) * r.iz;
+    n1 = fmaxf(n1, fminf(t0, t1)); f1 = fminf(f1, fmaxf(t0, t1));
+    n1 = fmaxf(n1, r.tmin); f1 = fminf(f1, lim);
+    const bool h0 = (n0 <= f0) && (REF_KIND(ch.x) != REF_EMPTY);
+    const bool h1 = (n1 <= f1) && (REF_KIND(ch.y) != REF_EMPTY);
+    if (h0 && h1) {
+        const bool swap = n1 < n0;
+        trav_push(lds_stack, spill, sp, swap ? ch.x : ch.y);
+        return swap ? ch.y : ch.x;
+    }
+    if (h0) return ch.x;
+    if (h1) return ch.y;
+    return trav_pop(lds_stack, spill, sp);
+}
+
+// One single step (either one internal node or one leaf): the "if-if" schedule.
 template <bool ANY, bool COUNT>
-__device__ __forceinline__ bool traverse(const DevScene& sc, vec3 o, vec3 d, float tmin, float tmax, uint32_t* lds_stack, ClosestHit& best, TravCounters& cnt) {
+__device__ __forceinline__ bool trav_step(const DevScene& sc, const TravRay& r, uint32_t* lds_stack, uint32_t* spill, int& sp, uint32_t& cur,
+                                          ClosestHit& best, TravCounters& cnt, bool& occluded);
+
+// One round; returns true when the ray is finished (for ANY also when occluded,
+// reported through `occluded`).
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ bool trav_round(const DevScene& sc, const TravRay& r, uint32_t* lds_stack, uint32_t* spill, int& sp, uint32_t& cur,
+                                           ClosestHit& best, TravCounters& cnt, bool& occluded) {
+    while (REF_KIND(cur) == REF_INTERNAL) cur = trav_node<COUNT>(sc, r, cur, ANY ? r.tmax : best.t, lds_stack, spill, sp, cnt);
+    const uint32_t kind = REF_KIND(cur);
+    if (kind == REF_TRI) {
+        const uint32_t first = REF_FIRST(cur), count = REF_COUNT(cur);
+        for (uint32_t k = 0; k < count; ++k) {
+            if (COUNT) cnt.prims++;
+            if (ANY) {
+                if (any_tri(sc, first + k, r.o, r.d, r.tmin, r.tmax)) {
+                    occluded = true;
+                    return true;
+                }
+            } else {
+                accept_tri(sc, first + k, r.o, r.d, r.tmin, r.tmax, best);
+            }
+        }
+        cur = trav_pop(lds_stack, spill, sp);
+    } else if (kind == REF_SPHERE) {
+        const uint32_t first = REF_FIRST(cur), count = REF_COUNT(cur);
+        for (uint32_t k = 0; k < count; ++k) {
+            if (COUNT) cnt.prims++;
+            if (ANY) {
+                if (any_sphere(sc, first + k, r.o, r.d, r.tmin, r.tmax)) {
+                    occluded = true;
+                    return true;
+                }
+            } else {
+                accept_sphere(sc, first + k, r.o, r.d, r.tmin, r.tmax, best);
+            }
+        }
+        cur = trav_pop(lds_stack, spill, sp);
+    }
+    return cur == REF_DONE;
+}
+
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ bool trav_step(const DevScene& sc, const TravRay& r, uint32_t* lds_stack, uint32_t* spill, int& sp, uint32_t& cur,
+                                          ClosestHit& best, TravCounters& cnt, bool& occluded) {
+    if (REF_KIND(cur) == REF_INTERNAL) {
+        cur = trav_node<COUNT>(sc, r, cur, ANY ? r.tmax : best.t, lds_stack, spill, sp, cnt);
+        return cur == REF_DONE;
+    }
+    return trav_round<ANY, COUNT>(sc, r, lds_stack, spill, sp, cur, best, cnt, occluded);
+}
+
+// The same traversal as one tight loop for a thread that owns a single ray.
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ bool traverse_simple(const DevScene& sc, vec3 o, vec3 d, float tmin, float tmax, uint32_t* lds_stack, ClosestHit& best, TravCounters& cnt) {
     best.t = tmax;
     best.ref = HIT_MISS;
     best.prim = -1;

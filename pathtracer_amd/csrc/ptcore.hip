@@ -70,14 +70,16 @@ struct ptc_context {
     uint32_t contrib_samples = 0;
     uint32_t* queue[2] = {nullptr, nullptr};    // live paths of this / the next bounce
     uint32_t* hitq = nullptr;                   // paths of this bounce that hit something
-    uint32_t* qcount = nullptr;                 // [0..3] two {hit, next} pairs used alternately, [4] generate
-    unsigned long long* counters = nullptr;     // [0..3] traversal, [16 + 16*k] shadow-ray shards
+    uint32_t* qcount = nullptr;                 // two groups {hit, next, shadow, extend work, shadow work} used alternately, [16] generate
+    uint32_t resident_waves = 6144;
+    unsigned long long* counters = nullptr;     // [0..3] traversal nodes/prims (extension, shadow), [4] shadow rays
     uint32_t* h_count = nullptr;                // pinned
 
     // options
     int semantics = 0, seeding = 0, cull_zero = 1, profile = 0, count_trav = 0, brute_force = 0;
     uint32_t bounce_cap = 1024;
     uint64_t batch_paths = 8u << 20;
+    uint32_t tune_refill = 16, tune_mode = 0, tune_shadow = 3, tune_chunk = 0;  // shadow 3 = by BVH size
 
     PtcStats stats{};
     std::vector<hipEvent_t> ev_pool;
@@ -123,7 +125,7 @@ void freeTargets(ptc_context* c) {
 
 void freePaths(ptc_context* c) {
     for (void* p : {(void*)c->ps.o_seed, (void*)c->ps.d_depth, (void*)c->ps.thr, (void*)c->ps.L, (void*)c->ps.hit_t, (void*)c->ps.hit_ref,
-                    (void*)c->ps.contrib, (void*)c->queue[0], (void*)c->queue[1], (void*)c->hitq})
+                    (void*)c->ps.contrib, (void*)c->ps.sh_o, (void*)c->ps.sh_d, (void*)c->queue[0], (void*)c->queue[1], (void*)c->hitq})
         if (p) (void)hipFree(p);
     c->ps = PathState{};
     c->queue[0] = c->queue[1] = c->hitq = nullptr;
@@ -166,6 +168,8 @@ int ensurePaths(ptc_context* ctx, uint32_t capacity, uint32_t contrib_samples) {
     CHK(hipMalloc((void**)&ctx->ps.hit_t, (size_t)capacity * sizeof(float)));
     CHK(hipMalloc((void**)&ctx->ps.hit_ref, (size_t)capacity * sizeof(int32_t)));
     CHK(hipMalloc((void**)&ctx->ps.contrib, std::max<size_t>((size_t)capacity * contrib_samples * 3, 1) * sizeof(float)));
+    CHK(hipMalloc((void**)&ctx->ps.sh_o, std::max<size_t>((size_t)capacity * contrib_samples, 1) * sizeof(float4)));
+    CHK(hipMalloc((void**)&ctx->ps.sh_d, std::max<size_t>((size_t)capacity * contrib_samples, 1) * sizeof(float4)));
     CHK(hipMalloc((void**)&ctx->queue[0], (size_t)capacity * sizeof(uint32_t)));
     CHK(hipMalloc((void**)&ctx->queue[1], (size_t)capacity * sizeof(uint32_t)));
     CHK(hipMalloc((void**)&ctx->hitq, (size_t)capacity * sizeof(uint32_t)));
@@ -272,6 +276,12 @@ int makeParams(ptc_context* ctx, int frame_id, uint32_t w, uint32_t h, RenderPar
     rp.brute_force = ctx->brute_force;
     rp.root_light_samples = (uint32_t)(int)sqrtf((float)ctx->light_samples);
     rp.samples_per_path = samplesPerSegment(ctx, rp.root_light_samples);
+    rp.tune_refill = ctx->tune_refill;
+    rp.tune_mode = ctx->tune_mode;
+    // shadow rays end at very different times (any hit stops them): refilling waves pay off
+    // once the tree is deep enough for that to matter
+    rp.tune_shadow = ctx->tune_shadow == 3 ? (ctx->bvh.n_nodes > 256u ? 1u : 0u) : ctx->tune_shadow;
+    rp.tune_chunk = ctx->tune_chunk;
     return PTC_OK;
 }
 
@@ -284,37 +294,39 @@ int uploadLights(ptc_context* ctx) {
     return PTC_OK;
 }
 
-#define N_COUNTERS (16 + 16 * WF_SHADOW_SHARDS)
+#define N_COUNTERS 8
+#define N_QCOUNT 20
 
 // Trace every bounce of the paths in queue[0] (count0 of them).  Per bounce:
-// extend (-> hit queue), connect and shade over the hit queue (its length stays on
-// the device; the grids are sized by the bounce's path count), survivors -> next
-// queue, whose length is the one word read back.
+// extend + hit compaction, connect + shadow over the hit queue (queue lengths stay
+// on the device; the grids are sized by the bounce's path count), shade, survivors
+// -> next queue, whose length is the one word read back.
 int runBounces(ptc_context* ctx, const RenderParams& rp, const DevScene& sc, uint32_t count0, uint32_t sample_begin) {
     uint32_t count = count0;
     int cur = 0;
     uint32_t bounce = 0;
     const uint32_t S = rp.samples_per_path;
     while (count > 0) {
-        uint32_t* pair = ctx->qcount + 2 * (bounce & 1u);  // {hit count, next count}
-        CHK(hipMemsetAsync(pair, 0, 2 * sizeof(uint32_t), ctx->stream));
+        uint32_t* grp = ctx->qcount + 8 * (bounce & 1u);  // {hit count, next count, shadow-ray count, extend work, shadow work}
+        CHK(hipMemsetAsync(grp, 0, 5 * sizeof(uint32_t), ctx->stream));
         {
             Timed t(ctx, 0);
-            wf_extend(ctx->stream, rp, sc, ctx->ps, ctx->queue[cur], count, ctx->hitq, pair, ctx->count_trav != 0, ctx->counters);
+            wf_extend(ctx->stream, rp, sc, ctx->ps, ctx->queue[cur], count, ctx->hitq, grp, grp + 3, ctx->resident_waves, ctx->count_trav != 0, ctx->counters);
         }
         ctx->stats.extension_rays += count;
         ctx->stats.extend_launches++;
         if (S) {
             Timed t(ctx, 1);
-            wf_connect(ctx->stream, rp, sc, ctx->ps, ctx->hitq, pair, count, S, ctx->count_trav != 0, ctx->counters, ctx->counters + 16);
+            wf_connect(ctx->stream, rp, sc, ctx->ps, ctx->hitq, grp, count, S, grp + 2);
+            wf_shadow(ctx->stream, rp, sc, ctx->ps, grp + 2, (uint64_t)count * S, grp + 4, ctx->resident_waves, ctx->count_trav != 0, ctx->counters, ctx->counters + 4);
             ctx->stats.connect_launches++;
         }
         {
             Timed t(ctx, 2);
-            wf_shade(ctx->stream, rp, sc, ctx->ps, ctx->hitq, pair, count, ctx->npix_pad, sample_begin, ctx->segctr, ctx->queue[cur ^ 1], pair + 1);
+            wf_shade(ctx->stream, rp, sc, ctx->ps, ctx->hitq, grp, count, ctx->npix_pad, sample_begin, ctx->segctr, ctx->queue[cur ^ 1], grp + 1);
         }
         ctx->stats.shade_launches++;
-        CHK(hipMemcpyAsync(ctx->h_count, pair + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        CHK(hipMemcpyAsync(ctx->h_count, grp + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         CHK(hipStreamSynchronize(ctx->stream));
         CHK(hipGetLastError());
         count = *ctx->h_count;
@@ -357,12 +369,12 @@ int renderRange(ptc_context* ctx, int frame_id, uint32_t w, uint32_t h, int32_t 
         const uint32_t ns = (uint32_t)std::min<int64_t>((int64_t)per_batch, j1 - ja);
         const uint32_t n_paths = ns * ctx->npix_pad;
         const int seedL = rp.seeding == 0 ? 1 : 0;  // reference order: result += radiance per segment
-        CHK(hipMemsetAsync(ctx->qcount + 4, 0, sizeof(uint32_t), ctx->stream));
+        CHK(hipMemsetAsync(ctx->qcount + 16, 0, sizeof(uint32_t), ctx->stream));
         {
             Timed t(ctx, 3);
-            wf_generate(ctx->stream, rp, ctx->ps, ctx->npix_pad, n_paths, (uint32_t)ja, ctx->acc, ctx->segctr, seedL, ctx->queue[0], ctx->qcount + 4);
+            wf_generate(ctx->stream, rp, ctx->ps, ctx->npix_pad, n_paths, (uint32_t)ja, ctx->acc, ctx->segctr, seedL, ctx->queue[0], ctx->qcount + 16);
         }
-        CHK(hipMemcpyAsync(ctx->h_count, ctx->qcount + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        CHK(hipMemcpyAsync(ctx->h_count, ctx->qcount + 16, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         CHK(hipStreamSynchronize(ctx->stream));
         const uint32_t count0 = *ctx->h_count;
         ctx->stats.paths += count0;
@@ -427,10 +439,11 @@ int ptc_create(int device_ordinal, ptc_context** out) {
     };
     if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     ctx->stream = ctx->own_stream;
-    if ((e = hipMalloc((void**)&ctx->qcount, 8 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc((void**)&ctx->qcount, N_QCOUNT * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void**)&ctx->counters, N_COUNTERS * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMemset(ctx->counters, 0, N_COUNTERS * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
     if ((e = hipHostMalloc((void**)&ctx->h_count, sizeof(uint32_t))) != hipSuccess) return bail("hipHostMalloc", e);
+    ctx->resident_waves = wf_resident_waves(device_ordinal);
     *out = ctx;
     return PTC_OK;
 }
@@ -626,12 +639,12 @@ int ptc_primary_hits(ptc_context* ctx, uint32_t width, uint32_t height, PtcHitRe
     rc = ensurePaths(ctx, ctx->npix_pad, 0);
     if (rc) return rc;
     const DevScene sc = deviceScene(ctx);
-    CHK(hipMemsetAsync(ctx->qcount, 0, 8 * sizeof(uint32_t), ctx->stream));
+    CHK(hipMemsetAsync(ctx->qcount, 0, N_QCOUNT * sizeof(uint32_t), ctx->stream));
     CHK(hipMemsetAsync(ctx->ps.hit_ref, 0xFF, (size_t)ctx->npix_pad * sizeof(int32_t), ctx->stream));  // HIT_MISS
-    wf_generate(ctx->stream, rp, ctx->ps, ctx->npix_pad, ctx->npix_pad, 0u, ctx->acc, ctx->segctr, 0, ctx->queue[0], ctx->qcount + 4);
-    CHK(hipMemcpyAsync(ctx->h_count, ctx->qcount + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    wf_generate(ctx->stream, rp, ctx->ps, ctx->npix_pad, ctx->npix_pad, 0u, ctx->acc, ctx->segctr, 0, ctx->queue[0], ctx->qcount + 16);
+    CHK(hipMemcpyAsync(ctx->h_count, ctx->qcount + 16, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     CHK(hipStreamSynchronize(ctx->stream));
-    wf_extend(ctx->stream, rp, sc, ctx->ps, ctx->queue[0], *ctx->h_count, ctx->hitq, ctx->qcount, false, ctx->counters);
+    wf_extend(ctx->stream, rp, sc, ctx->ps, ctx->queue[0], *ctx->h_count, nullptr, nullptr, ctx->qcount + 3, ctx->resident_waves, false, ctx->counters);
     wf_hit_records(ctx->stream, rp, sc, ctx->ps, ctx->npix_pad, ctx->d_hits);
     CHK(hipMemcpyAsync(out, ctx->d_hits, (size_t)width * height * sizeof(PtcHitRecord), hipMemcpyDeviceToHost, ctx->stream));
     CHK(hipStreamSynchronize(ctx->stream));
@@ -701,6 +714,12 @@ int ptc_set_option(ptc_context* ctx, int option, int64_t value) {
         case PTC_OPT_PROFILE: ctx->profile = value != 0; break;
         case PTC_OPT_COUNT_TRAVERSAL: ctx->count_trav = value != 0; break;
         case PTC_OPT_BRUTE_FORCE: ctx->brute_force = value != 0; break;
+        case PTC_OPT_TUNE_TRAVERSAL:
+            ctx->tune_refill = std::max<uint32_t>(1u, std::min<uint32_t>(64u, (uint32_t)(value & 0xFF)));
+            ctx->tune_mode = (uint32_t)((value >> 8) & 0xF);
+            ctx->tune_shadow = (uint32_t)((value >> 12) & 0xF);
+            ctx->tune_chunk = (uint32_t)((value >> 16) & 0xFFFF) / 64u * 64u;
+            break;
         default: return fail(ctx, PTC_ERR_INVALID, "unknown option");
     }
     return PTC_OK;
@@ -717,8 +736,7 @@ int ptc_get_stats(ptc_context* ctx, PtcStats* out) {
     ctx->stats.prims_tested = h[1];
     ctx->stats.shadow_nodes_visited = h[2];
     ctx->stats.shadow_prims_tested = h[3];
-    ctx->stats.shadow_rays = 0;
-    for (int k = 0; k < WF_SHADOW_SHARDS; ++k) ctx->stats.shadow_rays += h[16 + 16 * k];
+    ctx->stats.shadow_rays = h[4];
     *out = ctx->stats;
     return PTC_OK;
 }

@@ -11,14 +11,19 @@
 
 void wf_generate(hipStream_t s, const RenderParams& rp, const PathState& ps, uint32_t npix_pad, uint32_t n_paths, uint32_t sample_begin,
                  const float* acc, uint32_t* segctr, int seed_L_from_acc, uint32_t* queue, uint32_t* qcount);
+// closest hits of queue[0..count) into the path slots; with hit_queue != nullptr also the
+// compacted queue of the paths that hit something (misses end there)
+// `work_counter` is a zeroed device word the waves reserve their spans from
 void wf_extend(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, uint32_t count, uint32_t* hit_queue,
-               uint32_t* hit_count, bool count_trav, unsigned long long* trav_counters);
-// connect / shade read the queue length from device memory (`count_ptr`); `max_count` sizes the grid
+               uint32_t* hit_count, uint32_t* work_counter, uint32_t resident_waves, bool count_trav, unsigned long long* trav_counters);
+uint32_t wf_resident_waves(int device);
+// connect / shadow / shade read their queue length from device memory (`count_ptr`); `max_*` sizes the grid
 void wf_connect(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, const uint32_t* count_ptr,
-                uint32_t max_count, uint32_t n_samples, bool count_trav, unsigned long long* trav_counters, unsigned long long* shadow_counter);
+                uint32_t max_count, uint32_t n_samples, uint32_t* shadow_count);
+void wf_shadow(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* count_ptr, uint64_t max_rays,
+               uint32_t* work_counter, uint32_t resident_waves, bool count_trav, unsigned long long* trav_counters, unsigned long long* shadow_total);
 void wf_shade(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, const uint32_t* count_ptr,
               uint32_t max_count, uint32_t npix_pad, uint32_t sample_begin, uint32_t* segctr, uint32_t* next_queue, uint32_t* next_count);
-#define WF_SHADOW_SHARDS 64  /* shadow-ray counter words, 16 x 8 bytes apart */
 void wf_accumulate(hipStream_t s, const RenderParams& rp, const PathState& ps, uint32_t npix_pad, uint32_t n_samples, float* acc, int replace);
 void wf_resolve(hipStream_t s, const float* acc, float* result, uint32_t n_pixels, int spp, float gamma, int frame_id);
 void wf_hit_records(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, uint32_t npix_pad, PtcHitRecord* out);

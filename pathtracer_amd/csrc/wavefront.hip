@@ -3,14 +3,20 @@
 //   k_generate   camera rays for a batch of (pixel, sample) paths
 //                (PinholeCamera.cu:37-51), 8x8 pixel tile per 64-lane wave
 //   k_extend     closest hit of every active path (rtTrace ray type 0:
-//                Triangle.cu / Sphere.cu over the BVH), LDS-resident stack
-//   k_connect    one thread per shadow ray of the segment (rtTrace ray type 1,
-//                any-hit of Common.cu:30-36) leaving the f*G term of that light
-//                sample, or 0 when occluded
+//                Triangle.cu / Sphere.cu over the BVH); LDS-resident stack,
+//                while-while rounds, idle lanes pull the next ray of the block's
+//                chunk through an LDS counter
+//   k_compact_hits  queue of the paths that hit something; a miss ends the path
+//                with the background colour (Common.cu:13-18)
+//   k_connect    one thread per light sample of the segment: builds the shadow
+//                ray and its f*G term; rays whose term is exactly 0 are dropped,
+//                the others are queued
+//   k_shadow     any-hit traversal of the queued shadow rays (rtTrace ray type 1,
+//                Common.cu:30-36); an occluded ray zeroes its term
 //   k_shade      the closest-hit program of the chosen integrator
 //                (RayTracer.cu) + the bounce-loop bookkeeping of
 //                PinholeCamera.cu:54-66; survivors are compacted into the next
-//                queue with a wave64 ballot / prefix count / one atomic per wave
+//                queue (wave64 ballot + popcount prefix, one atomic per block)
 //   k_accumulate per-pixel sum of the batch's samples, in sample order
 //   k_resolve    average, gamma, frame lerp (PinholeCamera.cu:70-80)
 //
@@ -23,9 +29,10 @@
 #include "shading.h"
 #include "wavefront.h"
 
+#include <algorithm>
+
 #define BLOCK TRAV_BLOCK
 #define GEN_BLOCK 1024   /* generate / shade: one queue atomic per 1024 paths */
-#define SHADOW_SHARDS 64  /* shadow-ray counter words, 128 B apart */
 
 // ---------------------------------------------------------------- helpers --
 
@@ -117,41 +124,162 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_generate(RenderParams rp, PathSta
 }
 
 // ------------------------------------------------------------------ extend --
-// Closest hit of every queued path.  Paths that hit something are appended to
-// `hit_queue` (the only ones the connect and shade kernels need to look at); a
-// miss ends the path right here: radiance = background colour, not scaled by the
-// throughput (Common.cu:13-18).
+
+// Work distribution of the two traversal kernels.  Each WAVE owns a span of
+// consecutive queue entries [pos, end) that it reserves from one global counter
+// (`wave_chunk` entries per atomic, so a few thousand atomics per launch); lanes
+// that finished their ray take the next entries of the span.  Everything here is
+// wave-uniform except the returned index (0xFFFFFFFF = nothing for this lane).
+struct WaveWork {
+    uint32_t pos, end;
+    bool drained;  // the global counter is past `count`
+};
+
+__device__ __forceinline__ uint32_t wave_fetch(WaveWork& w, bool idle, uint32_t* __restrict__ counter, uint32_t wave_chunk, uint32_t count) {
+    const uint32_t lane = __lane_id();
+    if (w.pos >= w.end && !w.drained) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(counter, wave_chunk);
+        base = __shfl(base, 0);
+        w.pos = base;
+        w.end = min(base + wave_chunk, count);
+        if (base >= count) {
+            w.drained = true;
+            w.pos = w.end = 0;
+        }
+    }
+    const unsigned long long mask = __ballot(idle);
+    const uint32_t take = min((uint32_t)__popcll(mask), w.end - w.pos);
+    const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    const uint32_t idx = (idle && rank < take) ? w.pos + rank : 0xFFFFFFFFu;
+    w.pos += take;
+    return idx;
+}
+
+// Closest hit of every queued path: hit_t / hit_ref of the path's slot.
 template <bool COUNT>
 __global__ __launch_bounds__(BLOCK) void k_extend(RenderParams rp, DevScene sc, PathState ps, const uint32_t* __restrict__ queue, uint32_t count,
-                                                  uint32_t* __restrict__ hit_queue, uint32_t* __restrict__ hit_count,
-                                                  unsigned long long* __restrict__ trav_counters) {
+                                                  uint32_t* __restrict__ work_counter, uint32_t wave_chunk, unsigned long long* __restrict__ trav_counters) {
+    __shared__ uint32_t stack[TRAV_LDS_STACK * BLOCK];
+    uint32_t* my_stack = stack + threadIdx.x;
+    uint32_t spill[TRAV_SPILL_STACK];
+    TravRay r;
+    ClosestHit best;
+    TravCounters cnt = {0u, 0u};
+    int sp = 0;
+    uint32_t cur = REF_DONE, p = 0;
+    bool active = false;
+    WaveWork w = {0u, 0u, false};
+    for (;;) {
+        const uint32_t nidle = (uint32_t)__popcll(__ballot(!active));
+        if (nidle >= rp.tune_refill && !(w.drained && w.pos >= w.end)) {
+            const uint32_t idx = wave_fetch(w, !active, work_counter, wave_chunk, count);
+            if (idx != 0xFFFFFFFFu) {
+                p = queue[idx];
+                const float4 o4 = ps.o_seed[p], d4 = ps.d_depth[p];
+                active = trav_init(sc, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), rp.cf.epsilon, PT_RAY_MAX, r, sp, cur, best);
+                if (!active) {  // NaN direction or empty scene: a miss
+                    ps.hit_t[p] = best.t;
+                    ps.hit_ref[p] = HIT_MISS;
+                }
+            }
+        }
+        if (!__any(active)) {
+            if (w.drained && w.pos >= w.end) break;
+            continue;
+        }
+        if (active) {
+            bool occluded = false;
+            const bool fin = rp.tune_mode == 2 ? trav_step<false, COUNT>(sc, r, my_stack, spill, sp, cur, best, cnt, occluded)
+                                               : trav_round<false, COUNT>(sc, r, my_stack, spill, sp, cur, best, cnt, occluded);
+            if (fin) {
+                ps.hit_t[p] = best.t;
+                ps.hit_ref[p] = best.ref;
+                active = false;
+            }
+        }
+    }
+    if (COUNT) {
+        atomicAdd(&trav_counters[0], (unsigned long long)cnt.nodes);
+        atomicAdd(&trav_counters[1], (unsigned long long)cnt.prims);
+    }
+}
+
+// One ray per thread, one tight traversal loop.  On this hardware it beats the
+// refilling variant above: the per-round bookkeeping of the latter costs more issue
+// slots than the idle lanes it recovers.
+template <bool COUNT>
+__global__ __launch_bounds__(BLOCK) void k_extend_static(RenderParams rp, DevScene sc, PathState ps, const uint32_t* __restrict__ queue, uint32_t count,
+                                                         unsigned long long* __restrict__ trav_counters) {
     __shared__ uint32_t stack[TRAV_LDS_STACK * BLOCK];
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t p = queue[i];
+    const float4 o4 = ps.o_seed[p], d4 = ps.d_depth[p];
+    ClosestHit best;
+    TravCounters cnt = {0u, 0u};
+    traverse_simple<false, COUNT>(sc, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), rp.cf.epsilon, PT_RAY_MAX, stack + threadIdx.x, best, cnt);
+    ps.hit_t[p] = best.t;
+    ps.hit_ref[p] = best.ref;
+    if (COUNT) {
+        atomicAdd(&trav_counters[0], (unsigned long long)cnt.nodes);
+        atomicAdd(&trav_counters[1], (unsigned long long)cnt.prims);
+    }
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(BLOCK) void k_shadow_static(RenderParams rp, DevScene sc, PathState ps, const uint32_t* __restrict__ count_ptr,
+                                                         unsigned long long* __restrict__ trav_counters, unsigned long long* __restrict__ shadow_total) {
+    __shared__ uint32_t stack[TRAV_LDS_STACK * BLOCK];
+    const uint32_t count = *count_ptr;
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i == 0) atomicAdd(shadow_total, (unsigned long long)count);
+    if (i >= count) return;
+    const float4 o4 = ps.sh_o[i], d4 = ps.sh_d[i];
+    ClosestHit tmp;
+    TravCounters cnt = {0u, 0u};
+    if (traverse_simple<true, COUNT>(sc, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), rp.cf.epsilon, o4.w, stack + threadIdx.x, tmp, cnt)) {
+        const size_t plane = (size_t)rp.samples_per_path * ps.capacity;
+        const uint32_t slot = f2u(d4.w);
+        ps.contrib[slot] = 0.f;
+        ps.contrib[slot + plane] = 0.f;
+        ps.contrib[slot + 2 * plane] = 0.f;
+    }
+    if (COUNT) {
+        atomicAdd(&trav_counters[2], (unsigned long long)cnt.nodes);
+        atomicAdd(&trav_counters[3], (unsigned long long)cnt.prims);
+    }
+}
+
+// Brute force over all primitives (parity aid).
+__global__ __launch_bounds__(BLOCK) void k_extend_brute(RenderParams rp, DevScene sc, PathState ps, const uint32_t* __restrict__ queue, uint32_t count) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t p = queue[i];
+    const float4 o4 = ps.o_seed[p], d4 = ps.d_depth[p];
+    ClosestHit best;
+    brute_force<false>(sc, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), rp.cf.epsilon, PT_RAY_MAX, best);
+    ps.hit_t[p] = best.t;
+    ps.hit_ref[p] = best.ref;
+}
+
+// Paths that hit something go to `hit_queue` (the only ones the connect and shade
+// kernels look at); a miss ends the path right here: radiance = background
+// colour, not scaled by the throughput (Common.cu:13-18).
+__global__ __launch_bounds__(GEN_BLOCK) void k_compact_hits(RenderParams rp, PathState ps, const uint32_t* __restrict__ queue, uint32_t count,
+                                                        uint32_t* __restrict__ hit_queue, uint32_t* __restrict__ hit_count) {
+    const uint32_t i = blockIdx.x * GEN_BLOCK + threadIdx.x;
     bool hit = false;
     uint32_t p = 0;
     if (i < count) {
         p = queue[i];
-        const float4 o4 = ps.o_seed[p], d4 = ps.d_depth[p];
-        const vec3 o = mk3(o4.x, o4.y, o4.z), d = mk3(d4.x, d4.y, d4.z);
-        ClosestHit best;
-        TravCounters cnt = {0u, 0u};
-        if (rp.brute_force)
-            brute_force<false>(sc, o, d, rp.cf.epsilon, PT_RAY_MAX, best);
-        else
-            traverse<false, COUNT>(sc, o, d, rp.cf.epsilon, PT_RAY_MAX, stack + threadIdx.x, best, cnt);
-        ps.hit_t[p] = best.t;
-        ps.hit_ref[p] = best.ref;
-        hit = best.ref != HIT_MISS;
+        hit = ps.hit_ref[p] != HIT_MISS;
         if (!hit && (rp.bg[0] != 0.f || rp.bg[1] != 0.f || rp.bg[2] != 0.f)) {
             float4 L = ps.L[p];
             L.x += rp.bg[0];
             L.y += rp.bg[1];
             L.z += rp.bg[2];
             ps.L[p] = L;
-        }
-        if (COUNT) {
-            atomicAdd(&trav_counters[0], (unsigned long long)cnt.nodes);
-            atomicAdd(&trav_counters[1], (unsigned long long)cnt.prims);
         }
     }
     queue_append(hit, p, hit_queue, hit_count);
@@ -162,38 +290,46 @@ __global__ __launch_bounds__(BLOCK) void k_extend(RenderParams rp, DevScene sc, 
 __device__ __forceinline__ const PtcMaterialValue& material_of(const DevScene& sc, uint32_t mat) { return sc.materials[mat & ~MAT_LIGHT_BIT]; }
 __device__ __forceinline__ bool is_light(uint32_t mat) { return (mat & MAT_LIGHT_BIT) != 0u; }
 
-template <int INTEG, bool COUNT>
+// Position of light sample q's term for path p: three planes of
+// samples_per_path * capacity floats.
+__device__ __forceinline__ uint32_t contrib_slot(const PathState& ps, uint32_t p, uint32_t q) { return q * ps.capacity + p; }
+
+// One thread per (path with a hit, light sample).  Computes the shadow ray and the
+// term the reference adds when that ray is unoccluded (f_brdf*G for the quad-light
+// integrators, the Blinn-Phong term for `raytracer`).  A term that is exactly zero
+// adds nothing whether or not the ray is blocked, so no ray is queued for it; any
+// other value (NaN included) is stored and its ray queued; k_shadow zeroes the
+// term of an occluded ray.
+template <int INTEG>
 __global__ __launch_bounds__(BLOCK) void k_connect(RenderParams rp, DevScene sc, PathState ps, const uint32_t* __restrict__ queue,
-                                                   const uint32_t* __restrict__ count_ptr, uint32_t n_samples,
-                                                   unsigned long long* __restrict__ trav_counters, unsigned long long* __restrict__ shadow_counter) {
-    __shared__ uint32_t stack[TRAV_LDS_STACK * BLOCK];
-    const uint32_t count = *count_ptr;  // hits of this bounce, written by k_extend
+                                                   const uint32_t* __restrict__ count_ptr, uint32_t n_samples, uint32_t* __restrict__ shadow_count) {
+    const uint32_t count = *count_ptr;  // hits of this bounce, written by k_compact_hits
     const uint64_t tid = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (tid >= (uint64_t)count * n_samples) return;
-    const uint32_t i = (uint32_t)(tid % count), q = (uint32_t)(tid / count);
-    const uint32_t p = queue[i];
-    float* out = ps.contrib + (size_t)q * 3u * ps.capacity + p;
+    const bool valid = tid < (uint64_t)count * n_samples;
     vec3 term = mk3(0.f);
-    const int ref = ps.hit_ref[p];
-    bool traced = false;
-    if (ref != HIT_MISS) {
+    vec3 sh_o = mk3(0.f), sh_d = mk3(0.f);
+    float sh_tmax = 0.f;
+    uint32_t slot = 0;
+    bool need_ray = false;
+    if (valid) {
+        const uint32_t i = (uint32_t)(tid % count), q = (uint32_t)(tid / count);
+        const uint32_t p = queue[i];
+        slot = contrib_slot(ps, p, q);
         const float4 o4 = ps.o_seed[p], d4 = ps.d_depth[p];
         const vec3 o = mk3(o4.x, o4.y, o4.z), d = mk3(d4.x, d4.y, d4.z);
         const uint32_t seed = f2u(o4.w), depth = f2u(d4.w);
         HitAttr at;
-        hit_attributes(sc, ref, ps.hit_t[p], o, d, at);
+        hit_attributes(sc, ps.hit_ref[p], ps.hit_t[p], o, d, at);
         const PtcMaterialValue& mv = material_of(sc, at.mat);
         const PtcConfig& cf = rp.cf;
         bool skip = false;
-        if (INTEG == INT_DIRECT) skip = is_light(at.mat);                                   // RayTracer.cu:160-165
+        if (INTEG == INT_DIRECT) skip = is_light(at.mat);                                           // RayTracer.cu:160-165
         if (INTEG == INT_PATHTRACER) skip = cf.next_event_est && is_light(at.mat) && depth != 0u;  // :528-533
-        if (INTEG == INT_PATHTRACER2) skip = depth > 0u && is_light(at.mat);               // :436-441
+        if (INTEG == INT_PATHTRACER2) skip = depth > 0u && is_light(at.mat);                       // :436-441
         if (!skip) {
-            vec3 sh_o, sh_d;
-            float sh_tmin = cf.epsilon, sh_tmax;
             vec3 light_pos = mk3(0.f);
             QuadFrame qf;
-            uint32_t k = 0;
+            qf.a = qf.ab = qf.ac = mk3(0.f);
             if (INTEG == INT_RAYTRACER) {
                 // RayTracer.cu:42-86: point lights, then directional lights
                 if (q < sc.n_plights) {
@@ -205,11 +341,21 @@ __global__ __launch_bounds__(BLOCK) void k_connect(RenderParams rp, DevScene sc,
                     sh_tmax = PT_RAY_MAX;
                 }
                 sh_o = at.P + sh_d * cf.epsilon;
+                const vec3 H = normalize(sh_d + at.wo);
+                vec3 I = P3v(mv.diffuse) * fmaxf(dot(at.normal, sh_d), 0);
+                I += P3v(mv.specular) * powf(fmaxf(dot(at.normal, H), 0), mv.shininess);
+                if (q < sc.n_plights) {
+                    const float lightDist = sh_tmax;
+                    const float att = dot(P3v(sc.plights[q].attenuation), mk3(1, lightDist, lightDist * lightDist));
+                    I *= P3v(sc.plights[q].color) / att;
+                } else {
+                    I *= P3v(sc.dlights[q - sc.n_plights].color);
+                }
+                term = I;
             } else {
                 const int root = (int)rp.root_light_samples;
                 const uint32_t per_light = (uint32_t)(root * root);
-                k = q / per_light;
-                const uint32_t r = q % per_light;
+                const uint32_t k = q / per_light, r = q % per_light;
                 const int si = (int)(r / (uint32_t)root), sj = (int)(r % (uint32_t)root);
                 const PtcQuadLight& ql = sc.qlights[k];
                 qf.a = P3v(ql.tri1.v1);
@@ -228,33 +374,7 @@ __global__ __launch_bounds__(BLOCK) void k_connect(RenderParams rp, DevScene sc,
                 sh_o = at.P;
                 sh_d = normalize(light_pos - sh_o);
                 sh_tmax = length(light_pos - sh_o) - cf.epsilon;
-            }
-            ClosestHit tmp;
-            TravCounters cnt = {0u, 0u};
-            bool occluded;
-            if (rp.brute_force)
-                occluded = brute_force<true>(sc, sh_o, sh_d, sh_tmin, sh_tmax, tmp);
-            else
-                occluded = traverse<true, COUNT>(sc, sh_o, sh_d, sh_tmin, sh_tmax, stack + threadIdx.x, tmp, cnt);
-            traced = true;
-            if (COUNT) {
-                atomicAdd(&trav_counters[2], (unsigned long long)cnt.nodes);
-                atomicAdd(&trav_counters[3], (unsigned long long)cnt.prims);
-            }
-            if (!occluded) {
-                if (INTEG == INT_RAYTRACER) {
-                    const vec3 H = normalize(sh_d + at.wo);
-                    vec3 I = P3v(mv.diffuse) * fmaxf(dot(at.normal, sh_d), 0);
-                    I += P3v(mv.specular) * powf(fmaxf(dot(at.normal, H), 0), mv.shininess);
-                    if (q < sc.n_plights) {
-                        const float lightDist = sh_tmax;
-                        const float att = dot(P3v(sc.plights[q].attenuation), mk3(1, lightDist, lightDist * lightDist));
-                        I *= P3v(sc.plights[q].color) / att;
-                    } else {
-                        I *= P3v(sc.dlights[q - sc.n_plights].color);
-                    }
-                    term = I;
-                } else if (INTEG == INT_DIRECT) {
+                if (INTEG == INT_DIRECT) {
                     // RayTracer.cu:204-221
                     const vec3 wdir = normalize(light_pos - sh_o);
                     const vec3 f_brdf = (P3v(mv.diffuse) / PT_PIf) +
@@ -268,11 +388,11 @@ __global__ __launch_bounds__(BLOCK) void k_connect(RenderParams rp, DevScene sc,
                 } else if (INTEG == INT_PATHTRACER) {
                     // RayTracer.cu:745-776
                     const vec3 n = normalize(at.normal);
-                    const vec3 r = normalize(reflect(-at.wo, at.normal));
+                    const vec3 rr = normalize(reflect(-at.wo, at.normal));
                     const vec3 w_i_dir = normalize(light_pos - sh_o);
                     vec3 f_brdf = mk3(.0f);
                     if (mv.brdf_type == PTC_MOD_PHONG) {
-                        f_brdf = phong_brdf(w_i_dir, r, mv.shininess, P3v(mv.diffuse), P3v(mv.specular));
+                        f_brdf = phong_brdf(w_i_dir, rr, mv.shininess, P3v(mv.diffuse), P3v(mv.specular));
                     } else {
                         const float wi_dot_n_dir = dot(w_i_dir, n);
                         const float wo_dot_n_dir = dot(at.wo, n);
@@ -297,15 +417,102 @@ __global__ __launch_bounds__(BLOCK) void k_connect(RenderParams rp, DevScene sc,
                     term = f_brdf * G;
                 }
             }
+            need_ray = !(term.x == 0.f && term.y == 0.f && term.z == 0.f);
+        }
+        const size_t plane = (size_t)rp.samples_per_path * ps.capacity;
+        ps.contrib[slot] = term.x;
+        ps.contrib[slot + plane] = term.y;
+        ps.contrib[slot + 2 * plane] = term.z;
+    }
+    // queue the shadow ray
+    __shared__ uint32_t s_cnt[BLOCK / 64];
+    __shared__ uint32_t s_base;
+    const unsigned long long mask = __ballot(need_ray);
+    const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+    if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < BLOCK / 64; ++w) total += s_cnt[w];
+        s_base = total ? atomicAdd(shadow_count, total) : 0u;
+    }
+    __syncthreads();
+    if (need_ray) {
+        uint32_t at_ = s_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        for (uint32_t w = 0; w < wave; ++w) at_ += s_cnt[w];
+        ps.sh_o[at_] = make_float4(sh_o.x, sh_o.y, sh_o.z, sh_tmax);
+        ps.sh_d[at_] = make_float4(sh_d.x, sh_d.y, sh_d.z, u2f(slot));
+    }
+}
+
+// ------------------------------------------------------------------ shadow --
+// Any-hit traversal of the queued shadow rays, same work distribution as k_extend.
+template <bool COUNT>
+__global__ __launch_bounds__(BLOCK) void k_shadow(RenderParams rp, DevScene sc, PathState ps, const uint32_t* __restrict__ count_ptr,
+                                                  uint32_t* __restrict__ work_counter, uint32_t wave_chunk, unsigned long long* __restrict__ trav_counters,
+                                                  unsigned long long* __restrict__ shadow_total) {
+    __shared__ uint32_t stack[TRAV_LDS_STACK * BLOCK];
+    const uint32_t count = *count_ptr;
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(shadow_total, (unsigned long long)count);
+    const size_t plane = (size_t)rp.samples_per_path * ps.capacity;
+    uint32_t* my_stack = stack + threadIdx.x;
+    uint32_t spill[TRAV_SPILL_STACK];
+    TravRay r;
+    ClosestHit best;
+    TravCounters cnt = {0u, 0u};
+    int sp = 0;
+    uint32_t cur = REF_DONE, slot = 0;
+    bool active = false;
+    WaveWork w = {0u, 0u, false};
+    for (;;) {
+        const uint32_t nidle = (uint32_t)__popcll(__ballot(!active));
+        if (nidle >= rp.tune_refill && !(w.drained && w.pos >= w.end)) {
+            const uint32_t idx = wave_fetch(w, !active, work_counter, wave_chunk, count);
+            if (idx != 0xFFFFFFFFu) {
+                const float4 o4 = ps.sh_o[idx], d4 = ps.sh_d[idx];
+                slot = f2u(d4.w);
+                active = trav_init(sc, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), rp.cf.epsilon, o4.w, r, sp, cur, best);
+            }
+        }
+        if (!__any(active)) {
+            if (w.drained && w.pos >= w.end) break;
+            continue;
+        }
+        if (active) {
+            bool occluded = false;
+            const bool fin = rp.tune_shadow == 2 ? trav_step<true, COUNT>(sc, r, my_stack, spill, sp, cur, best, cnt, occluded)
+                                                 : trav_round<true, COUNT>(sc, r, my_stack, spill, sp, cur, best, cnt, occluded);
+            if (fin) {
+                if (occluded) {
+                    ps.contrib[slot] = 0.f;
+                    ps.contrib[slot + plane] = 0.f;
+                    ps.contrib[slot + 2 * plane] = 0.f;
+                }
+                active = false;
+            }
         }
     }
-    out[0] = term.x;
-    out[ps.capacity] = term.y;
-    out[2u * (size_t)ps.capacity] = term.z;
-    // shadow-ray count: one atomic per wave, spread over SHADOW_SHARDS words
-    const unsigned long long m = __ballot(traced);
-    if (m && __lane_id() == (uint32_t)(__ffsll((long long)m) - 1))
-        atomicAdd(shadow_counter + 16u * (blockIdx.x % SHADOW_SHARDS), (unsigned long long)__popcll(m));
+    if (COUNT) {
+        atomicAdd(&trav_counters[2], (unsigned long long)cnt.nodes);
+        atomicAdd(&trav_counters[3], (unsigned long long)cnt.prims);
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_shadow_brute(RenderParams rp, DevScene sc, PathState ps, const uint32_t* __restrict__ count_ptr,
+                                                        unsigned long long* __restrict__ shadow_total) {
+    const uint32_t count = *count_ptr;
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i == 0) atomicAdd(shadow_total, (unsigned long long)count);
+    if (i >= count) return;
+    const float4 o4 = ps.sh_o[i], d4 = ps.sh_d[i];
+    ClosestHit tmp;
+    if (brute_force<true>(sc, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), rp.cf.epsilon, o4.w, tmp)) {
+        const size_t plane = (size_t)rp.samples_per_path * ps.capacity;
+        const uint32_t slot = f2u(d4.w);
+        ps.contrib[slot] = 0.f;
+        ps.contrib[slot + plane] = 0.f;
+        ps.contrib[slot + 2 * plane] = 0.f;
+    }
 }
 
 // ------------------------------------------------------------------- shade --
@@ -315,9 +522,10 @@ struct Segment {
     bool done;
 };
 
-__device__ __forceinline__ vec3 contrib_at(const PathState& ps, uint32_t p, uint32_t q) {
-    const float* c = ps.contrib + (size_t)q * 3u * ps.capacity + p;
-    return mk3(c[0], c[ps.capacity], c[2u * (size_t)ps.capacity]);
+__device__ __forceinline__ vec3 contrib_at(const RenderParams& rp, const PathState& ps, uint32_t p, uint32_t q) {
+    const size_t plane = (size_t)rp.samples_per_path * ps.capacity;
+    const float* c = ps.contrib + contrib_slot(ps, p, q);
+    return mk3(c[0], c[plane], c[2 * plane]);
 }
 
 // RayTracer.cu:34-105
@@ -325,7 +533,7 @@ __device__ __forceinline__ vec3 shade_raytracer(const RenderParams& rp, const De
     const PtcMaterialValue& mv = material_of(sc, at.mat);
     vec3 result = P3v(mv.ambient) + P3v(mv.emission);
     const uint32_t nl = sc.n_plights + sc.n_dlights;
-    for (uint32_t q = 0; q < nl; ++q) result += contrib_at(ps, p, q);  // occluded lights left 0
+    for (uint32_t q = 0; q < nl; ++q) result += contrib_at(rp, ps, p, q);  // occluded lights left 0
     const vec3 radiance = result * sg.thr;
     if (length(P3v(mv.specular)) > 0) {
         sg.o = at.P;
@@ -365,9 +573,9 @@ __device__ __forceinline__ vec3 shade_analytic(const RenderParams& rp, const Dev
 }
 
 // Sum of the light-sample terms of quad light k in loop order.
-__device__ __forceinline__ vec3 light_sum(const PathState& ps, uint32_t p, uint32_t k, uint32_t per_light) {
+__device__ __forceinline__ vec3 light_sum(const RenderParams& rp, const PathState& ps, uint32_t p, uint32_t k, uint32_t per_light) {
     vec3 s = mk3(.0f);
-    for (uint32_t r = 0; r < per_light; ++r) s += contrib_at(ps, p, k * per_light + r);
+    for (uint32_t r = 0; r < per_light; ++r) s += contrib_at(rp, ps, p, k * per_light + r);
     return s;
 }
 
@@ -388,7 +596,7 @@ __device__ __forceinline__ vec3 shade_direct(const RenderParams& rp, const DevSc
     const uint32_t per_light = rp.root_light_samples * rp.root_light_samples;
     for (uint32_t k = 0; k < sc.n_qlights; ++k) {
         const float area = fabsf(quad_area(sc.qlights[k], false));
-        result += P3v(sc.qlights[k].color) * light_sum(ps, p, k, per_light) * (area / (float)rp.light_samples);
+        result += P3v(sc.qlights[k].color) * light_sum(rp, ps, p, k, per_light) * (area / (float)rp.light_samples);
     }
     return result;
 }
@@ -406,7 +614,7 @@ __device__ __forceinline__ vec3 shade_pathtracer2(const RenderParams& rp, const 
     vec3 L_d = mk3(.0f);
     for (uint32_t k = 0; k < sc.n_qlights; ++k) {
         const float area = fabsf(quad_area(sc.qlights[k], true));
-        L_d += P3v(sc.qlights[k].color) * (area / (float)rp.light_samples) * light_sum(ps, p, k, per_light);
+        L_d += P3v(sc.qlights[k].color) * (area / (float)rp.light_samples) * light_sum(rp, ps, p, k, per_light);
     }
     uint32_t st = lcg_skip(sg.seed, 2u * per_light * sc.n_qlights);
     const float zeta1 = rnd(st), zeta2 = rnd(st);
@@ -488,7 +696,7 @@ __device__ __forceinline__ vec3 shade_pathtracer(const RenderParams& rp, const D
     if (cf.next_event_est) {  // :700-801
         const uint32_t per_light = rp.root_light_samples * rp.root_light_samples;
         for (uint32_t k = 0; k < sc.n_qlights; ++k) {
-            const vec3 sampled_result = light_sum(ps, p, k, per_light);
+            const vec3 sampled_result = light_sum(rp, ps, p, k, per_light);
             const float area = quad_area(sc.qlights[k], false);
             if (cf.next_event_est == PTC_NEE_MIS) {
                 // :782-794 as written: pdf_lights_k, D and h are never assigned, so
@@ -683,36 +891,75 @@ void wf_generate(hipStream_t s, const RenderParams& rp, const PathState& ps, uin
                        seed_L_from_acc, queue, qcount);
 }
 
-void wf_extend(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, uint32_t count, uint32_t* hit_queue,
-               uint32_t* hit_count, bool count_trav, unsigned long long* trav_counters) {
-    if (count == 0) return;
-    if (count_trav)
-        hipLaunchKernelGGL(k_extend<true>, dim3(blocks_for(count)), dim3(BLOCK), 0, s, rp, sc, ps, queue, count, hit_queue, hit_count, trav_counters);
-    else
-        hipLaunchKernelGGL(k_extend<false>, dim3(blocks_for(count)), dim3(BLOCK), 0, s, rp, sc, ps, queue, count, hit_queue, hit_count, trav_counters);
+// Grid and per-wave span of a traversal launch over (at most) n rays: enough waves to
+// fill the chip a few times over when n is large, one ray per lane when it is small.
+static void trav_geometry(uint64_t n, uint32_t resident_waves, uint32_t tune_chunk, uint32_t& blocks, uint32_t& wave_chunk) {
+    uint64_t chunk = n / ((uint64_t)resident_waves * 2u);
+    chunk = (chunk / 64u) * 64u;
+    chunk = std::max<uint64_t>(64u, std::min<uint64_t>(chunk, 512u));
+    if (tune_chunk) chunk = tune_chunk;
+    wave_chunk = (uint32_t)chunk;
+    const uint64_t waves = (n + chunk - 1) / chunk;
+    blocks = (uint32_t)std::min<uint64_t>((waves + 3) / 4, std::max<uint32_t>(resident_waves / 4u, 1u));
 }
 
-template <int INTEG>
-static void launch_connect(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, const uint32_t* count_ptr,
-                           uint32_t max_count, uint32_t n_samples, bool count_trav, unsigned long long* trav_counters, unsigned long long* shadow_counter) {
-    const uint64_t threads = (uint64_t)max_count * n_samples;
-    if (count_trav)
-        hipLaunchKernelGGL((k_connect<INTEG, true>), dim3(blocks_for(threads)), dim3(BLOCK), 0, s, rp, sc, ps, queue, count_ptr, n_samples, trav_counters, shadow_counter);
+void wf_extend(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, uint32_t count, uint32_t* hit_queue,
+               uint32_t* hit_count, uint32_t* work_counter, uint32_t resident_waves, bool count_trav, unsigned long long* trav_counters) {
+    if (count == 0) return;
+    uint32_t blocks, wave_chunk;
+    trav_geometry(count, resident_waves, rp.tune_chunk, blocks, wave_chunk);
+    if (rp.brute_force)
+        hipLaunchKernelGGL(k_extend_brute, dim3(blocks_for(count)), dim3(BLOCK), 0, s, rp, sc, ps, queue, count);
+    else if (rp.tune_mode == 0 && count_trav)
+        hipLaunchKernelGGL(k_extend_static<true>, dim3(blocks_for(count)), dim3(BLOCK), 0, s, rp, sc, ps, queue, count, trav_counters);
+    else if (rp.tune_mode == 0)
+        hipLaunchKernelGGL(k_extend_static<false>, dim3(blocks_for(count)), dim3(BLOCK), 0, s, rp, sc, ps, queue, count, trav_counters);
+    else if (count_trav)
+        hipLaunchKernelGGL(k_extend<true>, dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, queue, count, work_counter, wave_chunk, trav_counters);
     else
-        hipLaunchKernelGGL((k_connect<INTEG, false>), dim3(blocks_for(threads)), dim3(BLOCK), 0, s, rp, sc, ps, queue, count_ptr, n_samples, trav_counters, shadow_counter);
+        hipLaunchKernelGGL(k_extend<false>, dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, queue, count, work_counter, wave_chunk, trav_counters);
+    if (hit_queue)
+        hipLaunchKernelGGL(k_compact_hits, dim3(blocks_for(count, GEN_BLOCK)), dim3(GEN_BLOCK), 0, s, rp, ps, queue, count, hit_queue, hit_count);
 }
 
 // `count_ptr` (device) holds the number of queued paths; `max_count` bounds it and sizes the grid.
 void wf_connect(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, const uint32_t* count_ptr,
-                uint32_t max_count, uint32_t n_samples, bool count_trav, unsigned long long* trav_counters, unsigned long long* shadow_counter) {
+                uint32_t max_count, uint32_t n_samples, uint32_t* shadow_count) {
     if (max_count == 0 || n_samples == 0) return;
+    const dim3 g(blocks_for((uint64_t)max_count * n_samples)), b(BLOCK);
     switch (rp.integrator) {
-        case INT_RAYTRACER: launch_connect<INT_RAYTRACER>(s, rp, sc, ps, queue, count_ptr, max_count, n_samples, count_trav, trav_counters, shadow_counter); break;
-        case INT_DIRECT: launch_connect<INT_DIRECT>(s, rp, sc, ps, queue, count_ptr, max_count, n_samples, count_trav, trav_counters, shadow_counter); break;
-        case INT_PATHTRACER: launch_connect<INT_PATHTRACER>(s, rp, sc, ps, queue, count_ptr, max_count, n_samples, count_trav, trav_counters, shadow_counter); break;
-        case INT_PATHTRACER2: launch_connect<INT_PATHTRACER2>(s, rp, sc, ps, queue, count_ptr, max_count, n_samples, count_trav, trav_counters, shadow_counter); break;
+        case INT_RAYTRACER: hipLaunchKernelGGL(k_connect<INT_RAYTRACER>, g, b, 0, s, rp, sc, ps, queue, count_ptr, n_samples, shadow_count); break;
+        case INT_DIRECT: hipLaunchKernelGGL(k_connect<INT_DIRECT>, g, b, 0, s, rp, sc, ps, queue, count_ptr, n_samples, shadow_count); break;
+        case INT_PATHTRACER: hipLaunchKernelGGL(k_connect<INT_PATHTRACER>, g, b, 0, s, rp, sc, ps, queue, count_ptr, n_samples, shadow_count); break;
+        case INT_PATHTRACER2: hipLaunchKernelGGL(k_connect<INT_PATHTRACER2>, g, b, 0, s, rp, sc, ps, queue, count_ptr, n_samples, shadow_count); break;
         default: break;
     }
+}
+
+// Traces the shadow rays k_connect queued (their number is in device memory, at most `max_rays`).
+void wf_shadow(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* count_ptr, uint64_t max_rays,
+               uint32_t* work_counter, uint32_t resident_waves, bool count_trav, unsigned long long* trav_counters, unsigned long long* shadow_total) {
+    if (max_rays == 0) return;
+    uint32_t blocks, wave_chunk;
+    trav_geometry(max_rays, resident_waves, rp.tune_chunk, blocks, wave_chunk);
+    if (rp.brute_force)
+        hipLaunchKernelGGL(k_shadow_brute, dim3(blocks_for(max_rays)), dim3(BLOCK), 0, s, rp, sc, ps, count_ptr, shadow_total);
+    else if (rp.tune_shadow == 0 && count_trav)
+        hipLaunchKernelGGL(k_shadow_static<true>, dim3(blocks_for(max_rays)), dim3(BLOCK), 0, s, rp, sc, ps, count_ptr, trav_counters, shadow_total);
+    else if (rp.tune_shadow == 0)
+        hipLaunchKernelGGL(k_shadow_static<false>, dim3(blocks_for(max_rays)), dim3(BLOCK), 0, s, rp, sc, ps, count_ptr, trav_counters, shadow_total);
+    else if (count_trav)
+        hipLaunchKernelGGL(k_shadow<true>, dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, count_ptr, work_counter, wave_chunk, trav_counters, shadow_total);
+    else
+        hipLaunchKernelGGL(k_shadow<false>, dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, count_ptr, work_counter, wave_chunk, trav_counters, shadow_total);
+}
+
+// Waves of the traversal kernels that the device keeps resident at once.
+uint32_t wf_resident_waves(int device) {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_extend<false>, BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
+    return (uint32_t)per_cu * (uint32_t)cus * (BLOCK / 64);
 }
 
 void wf_shade(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, const uint32_t* count_ptr,
