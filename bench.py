@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--semantics", type=int, default=1, help="1 = intended (by-reference helpers), 0 = literal")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--batch", type=int, default=None, help="PTC_OPT_BATCH_PATHS")
+    ap.add_argument("--builder", type=int, default=None, help="PTC_OPT_BVH_BUILDER: 0 LBVH, 1 PLOC")
     ap.add_argument("--tune", type=lambda v: int(v, 0), default=None, help="PTC_OPT_TUNE_TRAVERSAL value (experiments)")
     args = ap.parse_args()
 
@@ -90,6 +92,10 @@ def main():
     opts = {_ffi.OPT_SEMANTICS: args.semantics, _ffi.OPT_SEEDING: 1}
     if args.tune is not None:
         opts[_ffi.OPT_TUNE_TRAVERSAL] = args.tune
+    if args.batch is not None:
+        opts[_ffi.OPT_BATCH_PATHS] = args.batch
+    if args.builder is not None:
+        opts[_ffi.OPT_BVH_BUILDER] = args.builder
     r = Renderer(scene, device=local_rank, options=opts)
     sums = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda")
     r.bind_sum_buffer(sums.data_ptr(), sums.numel() * 4)

@@ -144,7 +144,7 @@ enum {
      * contribution is radiance*throughput, RayTracer.cu:918). Default 1. */
     PTC_OPT_CULL_ZERO = 4,
     /* Maximum camera paths in flight per wavefront batch (rounded to whole
-     * samples over the image). Default 8388608. */
+     * samples over the image). Default 67108864 (about 11 GB of path state). */
     PTC_OPT_BATCH_PATHS = 5,
     /* 1 = bracket every kernel class with HIP events and sum the times. */
     PTC_OPT_PROFILE = 6,
@@ -158,7 +158,10 @@ enum {
      * waves + single steps, 3 (shadow only) = 1 for trees of more than 256 nodes else 0;
      * bits 16..31 queue entries a wave reserves per atomic (multiple of 64, 0 = auto).
      * Default 0x3010. */
-    PTC_OPT_TUNE_TRAVERSAL = 9
+    PTC_OPT_TUNE_TRAVERSAL = 9,
+    /* Hierarchy builder used by the next ptc_build: 0 = LBVH (Karras radix tree over
+     * Morton codes), 1 = PLOC (locally-ordered clustering, better trees; default). */
+    PTC_OPT_BVH_BUILDER = 10
 };
 
 /* ----------------------------------------------------------- entry points -- */

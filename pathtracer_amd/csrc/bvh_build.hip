@@ -222,6 +222,88 @@ __global__ void k_emit(const uint32_t* __restrict__ left, const uint32_t* __rest
     nodes[node_base + (uint32_t)newidx[i]] = out;
 }
 
+
+// ---- PLOC: parallel locally-ordered clustering (Meister & Bittner 2018) ------
+// Clusters live in Morton order.  Every iteration each cluster looks `radius`
+// positions to either side for the neighbour whose union box has the smallest
+// area; mutual nearest neighbours merge into a new node; the cluster array is
+// compacted (order preserved).  Tree nodes: leaves 0..n-1 (sorted position),
+// internal nodes n..2n-2 in creation order.
+__device__ __forceinline__ float union_area(const Box6& a, const Box6& b) {
+    const float dx = fmaxf(a.hi[0], b.hi[0]) - fminf(a.lo[0], b.lo[0]);
+    const float dy = fmaxf(a.hi[1], b.hi[1]) - fminf(a.lo[1], b.lo[1]);
+    const float dz = fmaxf(a.hi[2], b.hi[2]) - fminf(a.lo[2], b.lo[2]);
+    return dx * dy + dy * dz + dz * dx;
+}
+
+__global__ void k_ploc_init(const Box6* __restrict__ boxes, const uint32_t* __restrict__ sorted_prims, int n, float pad, Box6* __restrict__ node_box,
+                            int* __restrict__ cluster) {
+    const int i = blockIdx.x * BB + threadIdx.x;
+    if (i >= n) return;
+    Box6 b = boxes[sorted_prims[i]];
+    for (int k = 0; k < 3; ++k) {
+        b.lo[k] -= pad;
+        b.hi[k] += pad;
+    }
+    node_box[i] = b;
+    cluster[i] = i;
+}
+
+__global__ void k_ploc_nn(const int* __restrict__ cluster, int m, const Box6* __restrict__ node_box, int radius, int* __restrict__ nn) {
+    const int i = blockIdx.x * BB + threadIdx.x;
+    if (i >= m) return;
+    const Box6 me = node_box[cluster[i]];
+    float best = INFINITY;
+    int bj = -1;
+    const int lo = max(0, i - radius), hi = min(m - 1, i + radius);
+    for (int j = lo; j <= hi; ++j) {
+        if (j == i) continue;
+        const float a = union_area(me, node_box[cluster[j]]);
+        if (a < best) {  // ties keep the lowest position
+            best = a;
+            bj = j;
+        }
+    }
+    nn[i] = bj;
+}
+
+__global__ void k_ploc_merge(const int* __restrict__ cluster, const int* __restrict__ nn, int m, int n, Box6* __restrict__ node_box,
+                             int* __restrict__ left, int* __restrict__ right, int* __restrict__ node_count, int* __restrict__ cluster_out,
+                             int* __restrict__ valid) {
+    const int i = blockIdx.x * BB + threadIdx.x;
+    if (i >= m) return;
+    const int j = nn[i];
+    if (j >= 0 && nn[j] == i) {
+        if (i < j) {
+            const int idx = atomicAdd(node_count, 1);  // internal node n + idx
+            const int a = cluster[i], b = cluster[j];
+            left[idx] = a;
+            right[idx] = b;
+            const Box6 ba = node_box[a], bb = node_box[b];
+            Box6 u;
+            for (int k = 0; k < 3; ++k) {
+                u.lo[k] = fminf(ba.lo[k], bb.lo[k]);
+                u.hi[k] = fmaxf(ba.hi[k], bb.hi[k]);
+            }
+            node_box[n + idx] = u;
+            cluster_out[i] = n + idx;
+            valid[i] = 1;
+        } else {
+            valid[i] = 0;
+        }
+    } else {
+        cluster_out[i] = cluster[i];
+        valid[i] = 1;
+    }
+}
+
+__global__ void k_ploc_scatter(const int* __restrict__ cluster_out, const int* __restrict__ valid, const int* __restrict__ pos, int m,
+                               int* __restrict__ cluster_next) {
+    const int i = blockIdx.x * BB + threadIdx.x;
+    if (i >= m) return;
+    if (valid[i]) cluster_next[pos[i]] = cluster_out[i];
+}
+
 __global__ void k_pack_tris(const PtcTriangle* __restrict__ tris, const int32_t* __restrict__ slot_prim, uint32_t n, float4* __restrict__ tri_q) {
     const uint32_t s = blockIdx.x * BB + threadIdx.x;
     if (s >= n) return;
@@ -303,9 +385,135 @@ struct DevBuf {
     hipError_t alloc(size_t n) { return hipMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T)); }
 };
 
-// LBVH over the small primitives of one kind; writes emitted nodes to nodes[node_base..].
-std::string buildKind(hipStream_t s, const Box6* d_boxes, const std::vector<Box6>& boxes, uint32_t kind, float pad, BvhNode* d_nodes, uint32_t node_base,
-                      KindResult& res) {
+
+// Binary tree (leaves 0..n-1, internal n..2n-2 with left/right) -> traversal nodes.
+// Subtrees of <= BVH_LEAF_MAX primitives become leaves whose primitives get
+// consecutive slots; kept nodes are numbered so that the two children of a node
+// sit next to each other.  `order` receives the leaf index of every slot.
+void emitTree(const std::vector<int>& left, const std::vector<int>& right, const std::vector<Box6>& box, int n, int root, uint32_t kind, uint32_t node_base,
+              std::vector<BvhNode>& out, std::vector<int>& order, uint32_t& max_depth) {
+    std::vector<int> size(2 * (size_t)n - 1, 1);
+    {  // subtree sizes, children before parents
+        std::vector<int> stack{root}, post;
+        while (!stack.empty()) {
+            const int v = stack.back();
+            stack.pop_back();
+            post.push_back(v);
+            if (v >= n) {
+                stack.push_back(left[v - n]);
+                stack.push_back(right[v - n]);
+            }
+        }
+        for (size_t k = post.size(); k-- > 0;) {
+            const int v = post[k];
+            if (v >= n) size[v] = size[left[v - n]] + size[right[v - n]];
+        }
+    }
+    out.clear();
+    order.clear();
+    max_depth = 0;
+    struct Item {
+        int node;
+        uint32_t idx, depth;
+    };
+    std::vector<Item> work;
+    out.push_back(BvhNode());
+    work.push_back({root, 0u, 1u});
+    std::vector<int> leaves;
+    while (!work.empty()) {
+        const Item it = work.back();
+        work.pop_back();
+        max_depth = std::max(max_depth, it.depth);
+        const int ch[2] = {left[it.node - n], right[it.node - n]};
+        BvhNode nd;
+        std::memset(&nd, 0, sizeof(nd));
+        Item pending[2];
+        int npending = 0;
+        for (int c = 0; c < 2; ++c) {
+            const int v = ch[c];
+            uint32_t ref;
+            if (size[v] <= BVH_LEAF_MAX) {
+                const uint32_t first = (uint32_t)order.size();
+                leaves.assign(1, v);
+                while (!leaves.empty()) {
+                    const int u = leaves.back();
+                    leaves.pop_back();
+                    if (u < n) order.push_back(u);
+                    else {
+                        leaves.push_back(right[u - n]);
+                        leaves.push_back(left[u - n]);
+                    }
+                }
+                ref = MAKE_LEAF(kind, first, (uint32_t)size[v]);
+            } else {
+                const uint32_t idx = (uint32_t)out.size();
+                out.push_back(BvhNode());
+                pending[npending++] = {v, idx, it.depth + 1u};
+                ref = node_base + idx;
+            }
+            float* lo = c == 0 ? nd.lo0 : nd.lo1;
+            float* hi = c == 0 ? nd.hi0 : nd.hi1;
+            for (int k = 0; k < 3; ++k) {
+                lo[k] = box[v].lo[k];
+                hi[k] = box[v].hi[k];
+            }
+            nd.child[c] = ref;
+        }
+        out[it.idx] = nd;
+        for (int k = npending; k-- > 0;) work.push_back(pending[k]);
+    }
+}
+
+// PLOC over the n Morton-sorted primitives; returns the tree on the host.
+std::string plocBuild(hipStream_t s, const Box6* d_boxes, const uint32_t* d_sorted, int n, float pad, std::vector<int>& left, std::vector<int>& right,
+                      std::vector<Box6>& box, int& root) {
+    const int radius = 10;
+    DevBuf<Box6> node_box;
+    DevBuf<int> cl_a, cl_b, cl_out, nn, valid, pos, d_left, d_right, node_count;
+    HIPCHK(node_box.alloc(2 * (size_t)n)); HIPCHK(cl_a.alloc(n)); HIPCHK(cl_b.alloc(n)); HIPCHK(cl_out.alloc(n));
+    HIPCHK(nn.alloc(n)); HIPCHK(valid.alloc(n)); HIPCHK(pos.alloc(n)); HIPCHK(d_left.alloc(n)); HIPCHK(d_right.alloc(n)); HIPCHK(node_count.alloc(1));
+    HIPCHK(hipMemsetAsync(node_count.p, 0, sizeof(int), s));
+    hipLaunchKernelGGL(k_ploc_init, dim3(nblocks(n)), dim3(BB), 0, s, d_boxes, d_sorted, n, pad, node_box.p, cl_a.p);
+    size_t temp_bytes = 0;
+    HIPCHK(rocprim::exclusive_scan(nullptr, temp_bytes, valid.p, pos.p, 0, (size_t)n, rocprim::plus<int>(), s));
+    DevBuf<char> temp;
+    HIPCHK(temp.alloc(temp_bytes));
+    int m = n;
+    int* cur = cl_a.p;
+    int* nxt = cl_b.p;
+    for (int iter = 0; m > 1; ++iter) {
+        if (iter > 4 * n + 64) return "BVH build: clustering does not converge";
+        hipLaunchKernelGGL(k_ploc_nn, dim3(nblocks(m)), dim3(BB), 0, s, cur, m, node_box.p, radius, nn.p);
+        hipLaunchKernelGGL(k_ploc_merge, dim3(nblocks(m)), dim3(BB), 0, s, cur, nn.p, m, n, node_box.p, d_left.p, d_right.p, node_count.p, cl_out.p, valid.p);
+        size_t tb = temp_bytes;
+        HIPCHK(rocprim::exclusive_scan(temp.p, tb, valid.p, pos.p, 0, (size_t)m, rocprim::plus<int>(), s));
+        hipLaunchKernelGGL(k_ploc_scatter, dim3(nblocks(m)), dim3(BB), 0, s, cl_out.p, valid.p, pos.p, m, nxt);
+        int tail[2];
+        HIPCHK(hipMemcpyAsync(&tail[0], pos.p + (m - 1), sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(&tail[1], valid.p + (m - 1), sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        const int m2 = tail[0] + tail[1];
+        if (m2 >= m || m2 < 1) return "BVH build: clustering made no progress";
+        m = m2;
+        std::swap(cur, nxt);
+    }
+    left.resize(n - 1);
+    right.resize(n - 1);
+    box.resize(2 * (size_t)n - 1);
+    int h_count = 0;
+    HIPCHK(hipMemcpyAsync(&h_count, node_count.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&root, cur, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(left.data(), d_left.p, sizeof(int) * (n - 1), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(right.data(), d_right.p, sizeof(int) * (n - 1), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(box.data(), node_box.p, sizeof(Box6) * (2 * (size_t)n - 1), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (h_count != n - 1) return "BVH build: clustering produced a wrong node count";
+    return "";
+}
+
+// Tree over the small primitives of one kind (builder 0: LBVH, 1: PLOC); writes the emitted nodes to nodes[node_base..].
+std::string buildKind(hipStream_t s, const Box6* d_boxes, const std::vector<Box6>& boxes, uint32_t kind, float pad, int builder, BvhNode* d_nodes,
+                      uint32_t node_base, KindResult& res) {
     std::vector<uint32_t> small, big;
     classify(boxes, small, big);
     res.n_small = (uint32_t)small.size();
@@ -353,6 +561,27 @@ std::string buildKind(hipStream_t s, const Box6* d_boxes, const std::vector<Box6
         DevBuf<char> temp;
         HIPCHK(temp.alloc(temp_bytes));
         HIPCHK(rocprim::radix_sort_pairs(temp.p, temp_bytes, keys_in.p, keys_out.p, vals_in.p, vals_out.p, (size_t)n, 0, 63, s));
+        if (builder == 1) {
+            std::vector<int> h_left, h_right, order;
+            std::vector<Box6> h_box;
+            std::vector<BvhNode> h_nodes;
+            int root = 0;
+            std::string err = plocBuild(s, d_boxes, vals_out.p, n, pad, h_left, h_right, h_box, root);
+            if (!err.empty()) return err;
+            uint32_t depth = 0;
+            emitTree(h_left, h_right, h_box, n, root, kind, node_base, h_nodes, order, depth);
+            std::vector<uint32_t> h_sorted(n);
+            HIPCHK(hipMemcpyAsync(h_sorted.data(), vals_out.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipMemcpyAsync(d_nodes + node_base, h_nodes.data(), sizeof(BvhNode) * h_nodes.size(), hipMemcpyHostToDevice, s));
+            HIPCHK(hipStreamSynchronize(s));
+            res.max_depth = depth;
+            res.n_tree_nodes = (uint32_t)h_nodes.size();
+            res.has_tree = true;
+            res.tree_box = h_box[root];
+            for (int i = 0; i < n; ++i) res.slot_prim.push_back((int32_t)h_sorted[order[i]]);
+            for (uint32_t i : big) res.slot_prim.push_back((int32_t)i);
+            return "";
+        }
         hipLaunchKernelGGL(k_karras, dim3(nblocks(n - 1)), dim3(BB), 0, s, keys_out.p, n, left.p, right.p, first.p, last.p, parent.p);
         hipLaunchKernelGGL(k_leaf_boxes, dim3(nblocks(n)), dim3(BB), 0, s, d_boxes, vals_out.p, n, pad, node_box.p);
         HIPCHK(hipMemsetAsync(depth.p, 0, sizeof(uint32_t), s));
@@ -441,9 +670,9 @@ std::string bvh_build(hipStream_t s, const BvhBuildInput& in, BvhBuildOutput& ou
     HIPCHK(hipMalloc((void**)&out.nodes, max_nodes * sizeof(BvhNode)));
     HIPCHK(hipMemsetAsync(out.nodes, 0, max_nodes * sizeof(BvhNode), s));
     KindResult kt, ks;
-    std::string err = buildKind(s, d_tbox.p, tbox, REF_TRI, pad, out.nodes, TOP_NODES, kt);
+    std::string err = buildKind(s, d_tbox.p, tbox, REF_TRI, pad, in.builder, out.nodes, TOP_NODES, kt);
     if (!err.empty()) return err;
-    err = buildKind(s, d_sbox.p, sbox, REF_SPHERE, pad, out.nodes, TOP_NODES + kt.n_tree_nodes, ks);
+    err = buildKind(s, d_sbox.p, sbox, REF_SPHERE, pad, in.builder, out.nodes, TOP_NODES + kt.n_tree_nodes, ks);
     if (!err.empty()) return err;
     out.n_nodes = TOP_NODES + kt.n_tree_nodes + ks.n_tree_nodes;
     out.max_depth = std::max(kt.max_depth, ks.max_depth) + 2u;

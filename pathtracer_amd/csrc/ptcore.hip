@@ -10,6 +10,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -78,7 +80,8 @@ struct ptc_context {
     // options
     int semantics = 0, seeding = 0, cull_zero = 1, profile = 0, count_trav = 0, brute_force = 0;
     uint32_t bounce_cap = 1024;
-    uint64_t batch_paths = 8u << 20;
+    uint64_t batch_paths = 64u << 20;
+    int bvh_builder = 1;
     uint32_t tune_refill = 16, tune_mode = 0, tune_shadow = 3, tune_chunk = 0;  // shadow 3 = by BVH size
 
     PtcStats stats{};
@@ -576,6 +579,7 @@ int ptc_build(ptc_context* ctx) {
     in.n_spheres = (uint32_t)ctx->spheres.size();
     in.h_tri_mat = tmat.data();
     in.h_sph_mat = smat.data();
+    in.builder = ctx->bvh_builder;
     in.extra_extent = ctx->have_cfg ? std::max(fabsf(ctx->cfg.eye.x), std::max(fabsf(ctx->cfg.eye.y), fabsf(ctx->cfg.eye.z))) : 0.f;
     std::string err = bvh_build(ctx->stream, in, ctx->bvh);
     if (!err.empty()) {
@@ -714,6 +718,11 @@ int ptc_set_option(ptc_context* ctx, int option, int64_t value) {
         case PTC_OPT_PROFILE: ctx->profile = value != 0; break;
         case PTC_OPT_COUNT_TRAVERSAL: ctx->count_trav = value != 0; break;
         case PTC_OPT_BRUTE_FORCE: ctx->brute_force = value != 0; break;
+        case PTC_OPT_BVH_BUILDER:
+            if (value != 0 && value != 1) return fail(ctx, PTC_ERR_INVALID, "BVH builder must be 0 (LBVH) or 1 (PLOC)");
+            ctx->bvh_builder = (int)value;
+            ctx->built = false;
+            break;
         case PTC_OPT_TUNE_TRAVERSAL:
             ctx->tune_refill = std::max<uint32_t>(1u, std::min<uint32_t>(64u, (uint32_t)(value & 0xFF)));
             ctx->tune_mode = (uint32_t)((value >> 8) & 0xF);
@@ -737,6 +746,7 @@ int ptc_get_stats(ptc_context* ctx, PtcStats* out) {
     ctx->stats.shadow_nodes_visited = h[2];
     ctx->stats.shadow_prims_tested = h[3];
     ctx->stats.shadow_rays = h[4];
+    if (getenv("PTC_DEBUG_MAX")) fprintf(stderr, "[ptc] max nodes/ray %llu max prims/ray %llu\n", h[5], h[6]);
     *out = ctx->stats;
     return PTC_OK;
 }

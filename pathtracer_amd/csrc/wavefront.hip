@@ -224,6 +224,8 @@ __global__ __launch_bounds__(BLOCK) void k_extend_static(RenderParams rp, DevSce
     if (COUNT) {
         atomicAdd(&trav_counters[0], (unsigned long long)cnt.nodes);
         atomicAdd(&trav_counters[1], (unsigned long long)cnt.prims);
+        atomicMax(&trav_counters[5], (unsigned long long)cnt.nodes);
+        atomicMax(&trav_counters[6], (unsigned long long)cnt.prims);
     }
 }
 
