@@ -155,9 +155,10 @@ enum {
     /* Traversal scheduling knobs for experiments: bits 0..7 idle lanes of a wave that
      * trigger a refill (1..64); bits 8..11 extension rays, bits 12..15 shadow rays:
      * 0 = one ray per thread, 1 = refilling waves + while-while rounds, 2 = refilling
-     * waves + single steps, 3 (shadow only) = 1 for trees of more than 256 nodes else 0;
+     * waves + single steps, 3 = automatic (extension: 0 for camera rays, 1 for later
+     * bounces; shadow: 1);
      * bits 16..31 queue entries a wave reserves per atomic (multiple of 64, 0 = auto).
-     * Default 0x3010. */
+     * Default 0x1320. */
     PTC_OPT_TUNE_TRAVERSAL = 9,
     /* Hierarchy builder used by the next ptc_build: 0 = LBVH (Karras radix tree over
      * Morton codes), 1 = PLOC (locally-ordered clustering, better trees; default). */

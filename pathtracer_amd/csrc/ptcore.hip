@@ -82,7 +82,7 @@ struct ptc_context {
     uint32_t bounce_cap = 1024;
     uint64_t batch_paths = 64u << 20;
     int bvh_builder = 1;
-    uint32_t tune_refill = 16, tune_mode = 0, tune_shadow = 3, tune_chunk = 0;  // shadow 3 = by BVH size
+    uint32_t tune_refill = 32, tune_mode = 3, tune_shadow = 1, tune_chunk = 0;
 
     PtcStats stats{};
     std::vector<hipEvent_t> ev_pool;
@@ -283,7 +283,7 @@ int makeParams(ptc_context* ctx, int frame_id, uint32_t w, uint32_t h, RenderPar
     rp.tune_mode = ctx->tune_mode;
     // shadow rays end at very different times (any hit stops them): refilling waves pay off
     // once the tree is deep enough for that to matter
-    rp.tune_shadow = ctx->tune_shadow == 3 ? (ctx->bvh.n_nodes > 256u ? 1u : 0u) : ctx->tune_shadow;
+    rp.tune_shadow = ctx->tune_shadow == 3 ? 1u : ctx->tune_shadow;
     rp.tune_chunk = ctx->tune_chunk;
     return PTC_OK;
 }
@@ -314,7 +314,7 @@ int runBounces(ptc_context* ctx, const RenderParams& rp, const DevScene& sc, uin
         CHK(hipMemsetAsync(grp, 0, 5 * sizeof(uint32_t), ctx->stream));
         {
             Timed t(ctx, 0);
-            wf_extend(ctx->stream, rp, sc, ctx->ps, ctx->queue[cur], count, ctx->hitq, grp, grp + 3, ctx->resident_waves, ctx->count_trav != 0, ctx->counters);
+            wf_extend(ctx->stream, rp, sc, ctx->ps, ctx->queue[cur], count, ctx->hitq, grp, grp + 3, ctx->resident_waves, bounce == 0, ctx->count_trav != 0, ctx->counters);
         }
         ctx->stats.extension_rays += count;
         ctx->stats.extend_launches++;
@@ -648,7 +648,7 @@ int ptc_primary_hits(ptc_context* ctx, uint32_t width, uint32_t height, PtcHitRe
     wf_generate(ctx->stream, rp, ctx->ps, ctx->npix_pad, ctx->npix_pad, 0u, ctx->acc, ctx->segctr, 0, ctx->queue[0], ctx->qcount + 16);
     CHK(hipMemcpyAsync(ctx->h_count, ctx->qcount + 16, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     CHK(hipStreamSynchronize(ctx->stream));
-    wf_extend(ctx->stream, rp, sc, ctx->ps, ctx->queue[0], *ctx->h_count, nullptr, nullptr, ctx->qcount + 3, ctx->resident_waves, false, ctx->counters);
+    wf_extend(ctx->stream, rp, sc, ctx->ps, ctx->queue[0], *ctx->h_count, nullptr, nullptr, ctx->qcount + 3, ctx->resident_waves, true, false, ctx->counters);
     wf_hit_records(ctx->stream, rp, sc, ctx->ps, ctx->npix_pad, ctx->d_hits);
     CHK(hipMemcpyAsync(out, ctx->d_hits, (size_t)width * height * sizeof(PtcHitRecord), hipMemcpyDeviceToHost, ctx->stream));
     CHK(hipStreamSynchronize(ctx->stream));

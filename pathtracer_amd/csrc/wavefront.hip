@@ -906,15 +906,19 @@ static void trav_geometry(uint64_t n, uint32_t resident_waves, uint32_t tune_chu
 }
 
 void wf_extend(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, uint32_t count, uint32_t* hit_queue,
-               uint32_t* hit_count, uint32_t* work_counter, uint32_t resident_waves, bool count_trav, unsigned long long* trav_counters) {
+               uint32_t* hit_count, uint32_t* work_counter, uint32_t resident_waves, bool coherent, bool count_trav,
+               unsigned long long* trav_counters) {
     if (count == 0) return;
     uint32_t blocks, wave_chunk;
     trav_geometry(count, resident_waves, rp.tune_chunk, blocks, wave_chunk);
+    // mode 3: camera rays arrive in 8x8 pixel bundles and finish together, one ray per
+    // thread is fastest; scattered rays finish at very different times, refilling pays
+    const uint32_t mode = rp.tune_mode == 3 ? (coherent ? 0u : 1u) : rp.tune_mode;
     if (rp.brute_force)
         hipLaunchKernelGGL(k_extend_brute, dim3(blocks_for(count)), dim3(BLOCK), 0, s, rp, sc, ps, queue, count);
-    else if (rp.tune_mode == 0 && count_trav)
+    else if (mode == 0 && count_trav)
         hipLaunchKernelGGL(k_extend_static<true>, dim3(blocks_for(count)), dim3(BLOCK), 0, s, rp, sc, ps, queue, count, trav_counters);
-    else if (rp.tune_mode == 0)
+    else if (mode == 0)
         hipLaunchKernelGGL(k_extend_static<false>, dim3(blocks_for(count)), dim3(BLOCK), 0, s, rp, sc, ps, queue, count, trav_counters);
     else if (count_trav)
         hipLaunchKernelGGL(k_extend<true>, dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, queue, count, work_counter, wave_chunk, trav_counters);
