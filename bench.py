@@ -4,14 +4,15 @@
     python bench.py --gpus N --steps K --warmup W [--workload dragon|cornell|cornell_ggx]
 
 A step = one full render of the workload (every pixel x every sample) through the
-C ABI: generate -> (extend -> connect -> shade)* -> accumulate, plus, for N > 1, one
+C ABI: generate -> (extend -> connect -> shadow -> shade)* -> accumulate, plus, for N > 1, one
 RCCL reduce of the pre-gamma radiance sums to rank 0 and the resolve there.  Inputs
 (scene, BVH) are resident in HBM before the timed region.  With N > 1 every rank
 renders its own `spp` samples of every pixel (global sample indices
 [rank*spp, (rank+1)*spp), counter-based seeds), i.e. weak scaling.
 
 Prints ONE JSON line: Mrays/s (extension segments = paths x bounces, whole job), the
-roofline object of the dominant kernel (k_extend) and the CPU-oracle baseline.
+roofline object of the dominant kernel class (extension-ray traversal) and the
+CPU-oracle baseline.
 """
 import argparse
 import json
@@ -146,20 +147,32 @@ def main():
     ext_rays, shadow_rays, paths = (float(x) for x in counts)
 
     if rank == 0:
-        # k_extend, the dominant kernel: per extension ray it reads the queue entry (4 B) and
-        # the ray (2 x float4 = 32 B), writes the hit (t + ref = 8 B) and fetches 64 B per BVH
-        # node visited and 48 B per triangle tested.
+        # Extension-ray traversal (k_extend_static for camera rays, k_extend for later
+        # bounces) is the dominant kernel class.  Algorithmic bytes per extension ray: the
+        # queue entry (4 B) and the ray (2 x float4 = 32 B) read, the hit (t + ref = 8 B)
+        # written, 64 B per BVH node visited and 48 B per triangle tested.  The shadow-ray
+        # kernel is reported the same way (32 B ray record read, 12 B written when occluded).
         b_ext = 44.0 + 64.0 * nodes_per_ray + 48.0 * prims_per_ray
+        b_sh = 44.0 + 64.0 * snodes_per_ray + 48.0 * sprims_per_ray
         extend_s = st.extend_ms * 1e-3
         achieved = (b_ext * st.extension_rays / extend_s / 1e9) if extend_s > 0 else 0.0
+        launches = max(int(st.extend_launches), 1)
+        traffic = None
+        tpath = os.path.join(ROOT, "pmc_traffic.json")
+        if os.path.exists(tpath) and not (args.spp or args.size):
+            t = json.load(open(tpath))
+            if t.get("workload") == args.workload and "extend" in t:
+                traffic = round(t["extend"]["fetch_bytes_per_launch"] + t["extend"]["write_bytes_per_launch"], 1)
         roofline = {
-            "bound": "hbm", "kernel": "k_extend", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "bound": "hbm", "kernel": "k_extend_static + k_extend (extension-ray traversal)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "algorithmic_bytes_per_launch": round(b_ext * st.extension_rays / launches, 1),
             "bytes_per_ray": round(b_ext, 1), "nodes_per_ray": round(nodes_per_ray, 2), "prims_per_ray": round(prims_per_ray, 2),
-            "avg_launch_ms": round(st.extend_ms / max(st.extend_launches, 1), 4), "launches": int(st.extend_launches),
-            "rays_per_launch": round(st.extension_rays / max(st.extend_launches, 1), 1),
-            "kernel_ms": {"extend": round(st.extend_ms, 2), "connect": round(st.connect_ms, 2), "shade": round(st.shade_ms, 2), "other": round(st.other_ms, 2)},
-            "shadow_nodes_per_ray": round(snodes_per_ray, 2), "shadow_prims_per_ray": round(sprims_per_ray, 2),
+            "avg_launch_ms": round(st.extend_ms / launches, 4), "launches": int(st.extend_launches),
+            "rays_per_launch": round(st.extension_rays / launches, 1),
+            "kernel_ms": {"extend": round(st.extend_ms, 2), "connect+shadow": round(st.connect_ms, 2), "shade": round(st.shade_ms, 2), "other": round(st.other_ms, 2)},
+            "shadow": {"bytes_per_ray": round(b_sh, 1), "nodes_per_ray": round(snodes_per_ray, 2), "prims_per_ray": round(sprims_per_ray, 2),
+                       "rays": int(st.shadow_rays)},
         }
         cpu = None
         if not args.no_cpu_baseline and world == 1:

@@ -17,7 +17,11 @@ struct Cand {
 };
 
 // Triangle.cu:15-46.  q0=(v1,n.x) q1=(v2,n.y) q2=(v3,n.z).
-__device__ __forceinline__ Cand tri_candidate(float4 q0, float4 q1, float4 q2, vec3 o, vec3 d) {
+// [t_lo, t_hi] is the interval outside of which the caller discards the candidate
+// anyway (tmin < t < tmax, and t <= current closest distance): the barycentric part
+// is skipped for such t, which cannot change any result.  Likewise a negative
+// quotient is known from the signs of numerator and denominator before dividing.
+__device__ __forceinline__ Cand tri_candidate(float4 q0, float4 q1, float4 q2, vec3 o, vec3 d, float t_lo, float t_hi) {
     Cand c;
     c.hit = false;
     c.t = c.u = c.v = 0.f;
@@ -26,11 +30,15 @@ __device__ __forceinline__ Cand tri_candidate(float4 q0, float4 q1, float4 q2, v
     if (dot(d, n) >= .0f) n = -n;
     float nDotWo = dot(n, -d);
     if (nDotWo == 0.0f) return c;
-    float t = dot(v1 - o, n) / dot(d, n);
+    const float num = dot(v1 - o, n), den = dot(d, n);
+    // num/den < 0 rounds to a value <= -0 < 0.001: rejected by the test below
+    if ((num < 0.f && den > 0.f) || (num > 0.f && den < 0.f)) return c;
+    float t = num / den;
     vec3 P = o + t * d;
     // `t < 0.001` is a double comparison in the source; 0.001f is the smallest
     // float above the double 0.001, so the float comparison is equivalent.
     if (t < 0.001f) return c;
+    if (!(t > t_lo && t <= t_hi)) return c;
     vec3 tmp0 = v3 - v1, tmp1 = v2 - v1, tmp2 = P - v1;
     float d00 = dot(tmp0, tmp0), d01 = dot(tmp0, tmp1), d02 = dot(tmp0, tmp2);
     float d11 = dot(tmp1, tmp1), d12 = dot(tmp1, tmp2);
@@ -142,7 +150,7 @@ struct ClosestHit {
 
 __device__ __forceinline__ void accept_tri(const DevScene& sc, uint32_t slot, vec3 o, vec3 d, float tmin, float tmax, ClosestHit& best) {
     const float4* q = sc.tri_q + 3 * (size_t)slot;
-    Cand c = tri_candidate(q[0], q[1], q[2], o, d);
+    Cand c = tri_candidate(q[0], q[1], q[2], o, d, tmin, best.t);
     if (!c.hit || !(c.t > tmin && c.t < tmax)) return;
     if (best.ref != HIT_MISS && !(c.t < best.t)) {
         if (c.t != best.t) return;
@@ -176,7 +184,7 @@ __device__ __forceinline__ void accept_sphere(const DevScene& sc, uint32_t slot,
 
 __device__ __forceinline__ bool any_tri(const DevScene& sc, uint32_t slot, vec3 o, vec3 d, float tmin, float tmax) {
     const float4* q = sc.tri_q + 3 * (size_t)slot;
-    Cand c = tri_candidate(q[0], q[1], q[2], o, d);
+    Cand c = tri_candidate(q[0], q[1], q[2], o, d, tmin, tmax);
     return c.hit && c.t > tmin && c.t < tmax;
 }
 __device__ __forceinline__ bool any_sphere(const DevScene& sc, uint32_t slot, vec3 o, vec3 d, float tmin, float tmax) {
@@ -199,9 +207,16 @@ __device__ __forceinline__ bool dir_is_nan(vec3 d) { return (d.x != d.x) || (d.y
 // LDS array (entry i at lds_stack[i*TRAV_BLOCK]); deeper entries go to `spill`.
 struct TravRay {
     vec3 o, d;
-    float ix, iy, iz;  // 1/d
+    float ix, iy, iz;     // 1/d (see safe_inv)
+    float nox, noy, noz;  // -o/d
     float tmin, tmax;
 };
+
+// Reciprocal for the slab tests.  A zero component would give inf and then NaN in
+// lo*inv - o*inv; a huge finite value keeps the slab test meaningful, and the error it
+// introduces is far inside the padding of the boxes.  The slab arithmetic is allowed to
+// contract into FMAs (explicitly): only the primitive tests decide a hit.
+__device__ __forceinline__ float safe_inv(float d) { return fabsf(d) > 1e-30f ? 1.0f / d : copysignf(1e30f, d); }
 
 #define REF_DONE REF_EMPTY_WORD
 
@@ -222,9 +237,12 @@ __device__ __forceinline__ uint32_t trav_pop(const uint32_t* lds_stack, const ui
 __device__ __forceinline__ bool trav_init(const DevScene& sc, vec3 o, vec3 d, float tmin, float tmax, TravRay& r, int& sp, uint32_t& cur, ClosestHit& best) {
     r.o = o;
     r.d = d;
-    r.ix = 1.0f / d.x;
-    r.iy = 1.0f / d.y;
-    r.iz = 1.0f / d.z;
+    r.ix = safe_inv(d.x);
+    r.iy = safe_inv(d.y);
+    r.iz = safe_inv(d.z);
+    r.nox = -(o.x * r.ix);
+    r.noy = -(o.y * r.iy);
+    r.noz = -(o.z * r.iz);
     r.tmin = tmin;
     r.tmax = tmax;
     best.t = tmax;
@@ -245,19 +263,19 @@ __device__ __forceinline__ uint32_t trav_node(const DevScene& sc, const TravRay&
     const uint4 ch = *reinterpret_cast<const uint4*>(n4 + 3);
     if (COUNT) cnt.nodes++;
     // child 0: lo=(a.x,a.y,a.z) hi=(a.w,b.x,b.y)
-    float t0 = (a.x - r.o.x) * r.ix, t1 = (a.w - r.o.x) * r.ix;
+    float t0 = __builtin_fmaf(a.x, r.ix, r.nox), t1 = __builtin_fmaf(a.w, r.ix, r.nox);
     float n0 = fminf(t0, t1), f0 = fmaxf(t0, t1);
-    t0 = (a.y - r.o.y) * r.iy; t1 = (b.x - r.o.y) * r.iy;
+    t0 = __builtin_fmaf(a.y, r.iy, r.noy); t1 = __builtin_fmaf(b.x, r.iy, r.noy);
     n0 = fmaxf(n0, fminf(t0, t1)); f0 = fminf(f0, fmaxf(t0, t1));
-    t0 = (a.z - r.o.z) * r.iz; t1 = (b.y - r.o.z) * r.iz;
+    t0 = __builtin_fmaf(a.z, r.iz, r.noz); t1 = __builtin_fmaf(b.y, r.iz, r.noz);
     n0 = fmaxf(n0, fminf(t0, t1)); f0 = fminf(f0, fmaxf(t0, t1));
     n0 = fmaxf(n0, r.tmin); f0 = fminf(f0, lim);
     // child 1: lo=(b.z,b.w,c.x) hi=(c.y,c.z,c.w)
-    t0 = (b.z - r.o.x) * r.ix; t1 = (c.y - r.o.x) * r.ix;
+    t0 = __builtin_fmaf(b.z, r.ix, r.nox); t1 = __builtin_fmaf(c.y, r.ix, r.nox);
     float n1 = fminf(t0, t1), f1 = fmaxf(t0, t1);
-    t0 = (b.w - r.o.y) * r.iy; t1 = (c.z - r.o.y) * r.iy;
+    t0 = __builtin_fmaf(b.w, r.iy, r.noy); t1 = __builtin_fmaf(c.z, r.iy, r.noy);
     n1 = fmaxf(n1, fminf(t0, t1)); f1 = fminf(f1, fmaxf(t0, t1));
-    t0 = (c.x - r.o.z) * r.iz; t1 = (c.w - r.o.z) * r.iz;
+    t0 = __builtin_fmaf(c.x, r.iz, r.noz); t1 = __builtin_fmaf(c.w, r.iz, r.noz);
     n1 = fmaxf(n1, fminf(t0, t1)); f1 = fminf(f1, fmaxf(t0, t1));
     n1 = fmaxf(n1, r.tmin); f1 = fminf(f1, lim);
     const bool h0 = (n0 <= f0) && (REF_KIND(ch.x) != REF_EMPTY);
@@ -333,7 +351,8 @@ __device__ __forceinline__ bool traverse_simple(const DevScene& sc, vec3 o, vec3
     best.ref = HIT_MISS;
     best.prim = -1;
     if (dir_is_nan(d) || sc.n_nodes == 0) return false;
-    const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+    const float ix = safe_inv(d.x), iy = safe_inv(d.y), iz = safe_inv(d.z);
+    const float nox = -(o.x * ix), noy = -(o.y * iy), noz = -(o.z * iz);
     uint32_t spill[TRAV_SPILL_STACK];
     int sp = 0;
     uint32_t cur = 0;  // internal node 0 = root
@@ -346,19 +365,19 @@ __device__ __forceinline__ bool traverse_simple(const DevScene& sc, vec3 o, vec3
             if (COUNT) cnt.nodes++;
             const float lim = ANY ? tmax : best.t;
             // child 0: lo=(a.x,a.y,a.z) hi=(a.w,b.x,b.y)
-            float t0 = (a.x - o.x) * ix, t1 = (a.w - o.x) * ix;
+            float t0 = __builtin_fmaf(a.x, ix, nox), t1 = __builtin_fmaf(a.w, ix, nox);
             float n0 = fminf(t0, t1), f0 = fmaxf(t0, t1);
-            t0 = (a.y - o.y) * iy; t1 = (b.x - o.y) * iy;
+            t0 = __builtin_fmaf(a.y, iy, noy); t1 = __builtin_fmaf(b.x, iy, noy);
             n0 = fmaxf(n0, fminf(t0, t1)); f0 = fminf(f0, fmaxf(t0, t1));
-            t0 = (a.z - o.z) * iz; t1 = (b.y - o.z) * iz;
+            t0 = __builtin_fmaf(a.z, iz, noz); t1 = __builtin_fmaf(b.y, iz, noz);
             n0 = fmaxf(n0, fminf(t0, t1)); f0 = fminf(f0, fmaxf(t0, t1));
             n0 = fmaxf(n0, tmin); f0 = fminf(f0, lim);
             // child 1: lo=(b.z,b.w,c.x) hi=(c.y,c.z,c.w)
-            t0 = (b.z - o.x) * ix; t1 = (c.y - o.x) * ix;
+            t0 = __builtin_fmaf(b.z, ix, nox); t1 = __builtin_fmaf(c.y, ix, nox);
             float n1 = fminf(t0, t1), f1 = fmaxf(t0, t1);
-            t0 = (b.w - o.y) * iy; t1 = (c.z - o.y) * iy;
+            t0 = __builtin_fmaf(b.w, iy, noy); t1 = __builtin_fmaf(c.z, iy, noy);
             n1 = fmaxf(n1, fminf(t0, t1)); f1 = fminf(f1, fmaxf(t0, t1));
-            t0 = (c.x - o.z) * iz; t1 = (c.w - o.z) * iz;
+            t0 = __builtin_fmaf(c.x, iz, noz); t1 = __builtin_fmaf(c.w, iz, noz);
             n1 = fmaxf(n1, fminf(t0, t1)); f1 = fminf(f1, fmaxf(t0, t1));
             n1 = fmaxf(n1, tmin); f1 = fminf(f1, lim);
             const bool h0 = (n0 <= f0) && (REF_KIND(ch.x) != REF_EMPTY);

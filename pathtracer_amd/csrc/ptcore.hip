@@ -314,7 +314,11 @@ int runBounces(ptc_context* ctx, const RenderParams& rp, const DevScene& sc, uin
         CHK(hipMemsetAsync(grp, 0, 5 * sizeof(uint32_t), ctx->stream));
         {
             Timed t(ctx, 0);
-            wf_extend(ctx->stream, rp, sc, ctx->ps, ctx->queue[cur], count, ctx->hitq, grp, grp + 3, ctx->resident_waves, bounce == 0, ctx->count_trav != 0, ctx->counters);
+            wf_extend(ctx->stream, rp, sc, ctx->ps, ctx->queue[cur], count, grp + 3, ctx->resident_waves, bounce == 0, ctx->count_trav != 0, ctx->counters);
+        }
+        {
+            Timed t(ctx, 3);
+            wf_compact_hits(ctx->stream, rp, ctx->ps, ctx->queue[cur], count, ctx->hitq, grp);
         }
         ctx->stats.extension_rays += count;
         ctx->stats.extend_launches++;
@@ -332,6 +336,14 @@ int runBounces(ptc_context* ctx, const RenderParams& rp, const DevScene& sc, uin
         CHK(hipMemcpyAsync(ctx->h_count, grp + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         CHK(hipStreamSynchronize(ctx->stream));
         CHK(hipGetLastError());
+        if (ctx->count_trav && getenv("PTC_DEBUG_BOUNCES")) {
+            unsigned long long h[8];
+            uint32_t q[8];
+            (void)hipMemcpy(h, ctx->counters, sizeof(h), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(q, grp, sizeof(q), hipMemcpyDeviceToHost);
+            fprintf(stderr, "[ptc] bounce %u: rays %u hits %u shadow %u next %u | cumulative ext nodes %llu prims %llu shadow nodes %llu prims %llu\n", bounce,
+                    count, q[0], q[2], q[1], h[0], h[1], h[2], h[3]);
+        }
         count = *ctx->h_count;
         cur ^= 1;
         ++bounce;
@@ -648,7 +660,7 @@ int ptc_primary_hits(ptc_context* ctx, uint32_t width, uint32_t height, PtcHitRe
     wf_generate(ctx->stream, rp, ctx->ps, ctx->npix_pad, ctx->npix_pad, 0u, ctx->acc, ctx->segctr, 0, ctx->queue[0], ctx->qcount + 16);
     CHK(hipMemcpyAsync(ctx->h_count, ctx->qcount + 16, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     CHK(hipStreamSynchronize(ctx->stream));
-    wf_extend(ctx->stream, rp, sc, ctx->ps, ctx->queue[0], *ctx->h_count, nullptr, nullptr, ctx->qcount + 3, ctx->resident_waves, true, false, ctx->counters);
+    wf_extend(ctx->stream, rp, sc, ctx->ps, ctx->queue[0], *ctx->h_count, ctx->qcount + 3, ctx->resident_waves, true, false, ctx->counters);
     wf_hit_records(ctx->stream, rp, sc, ctx->ps, ctx->npix_pad, ctx->d_hits);
     CHK(hipMemcpyAsync(out, ctx->d_hits, (size_t)width * height * sizeof(PtcHitRecord), hipMemcpyDeviceToHost, ctx->stream));
     CHK(hipStreamSynchronize(ctx->stream));

@@ -11,12 +11,12 @@
 
 void wf_generate(hipStream_t s, const RenderParams& rp, const PathState& ps, uint32_t npix_pad, uint32_t n_paths, uint32_t sample_begin,
                  const float* acc, uint32_t* segctr, int seed_L_from_acc, uint32_t* queue, uint32_t* qcount);
-// closest hits of queue[0..count) into the path slots; with hit_queue != nullptr also the
+// closest hits of queue[0..count) into the path slots; `work_counter` is a zeroed device word
+// the refilling waves reserve their spans from; `coherent` = camera rays
+void wf_extend(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, uint32_t count, uint32_t* work_counter,
+               uint32_t resident_waves, bool coherent, bool count_trav, unsigned long long* trav_counters);
 // compacted queue of the paths that hit something (misses end there)
-// `work_counter` is a zeroed device word the waves reserve their spans from
-void wf_extend(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, uint32_t count, uint32_t* hit_queue,
-               uint32_t* hit_count, uint32_t* work_counter, uint32_t resident_waves, bool coherent, bool count_trav,
-               unsigned long long* trav_counters);
+void wf_compact_hits(hipStream_t s, const RenderParams& rp, const PathState& ps, const uint32_t* queue, uint32_t count, uint32_t* hit_queue, uint32_t* hit_count);
 uint32_t wf_resident_waves(int device);
 // connect / shadow / shade read their queue length from device memory (`count_ptr`); `max_*` sizes the grid
 void wf_connect(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, const uint32_t* count_ptr,

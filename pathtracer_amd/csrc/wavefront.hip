@@ -2,10 +2,14 @@
 //
 //   k_generate   camera rays for a batch of (pixel, sample) paths
 //                (PinholeCamera.cu:37-51), 8x8 pixel tile per 64-lane wave
-//   k_extend     closest hit of every active path (rtTrace ray type 0:
-//                Triangle.cu / Sphere.cu over the BVH); LDS-resident stack,
-//                while-while rounds, idle lanes pull the next ray of the block's
-//                chunk through an LDS counter
+//   k_extend_static / k_extend
+//                closest hit of every active path (rtTrace ray type 0:
+//                Triangle.cu / Sphere.cu over the BVH); LDS-resident stack.
+//                The static kernel (one ray per lane, tight loop) serves the
+//                coherent camera rays; the refilling kernel serves scattered
+//                rays: resident waves reserve spans of the queue from one global
+//                counter and lanes that finish pull the next ray of the span
+//   k_shadow_static / k_shadow  the same pair for any-hit shadow rays
 //   k_compact_hits  queue of the paths that hit something; a miss ends the path
 //                with the background colour (Common.cu:13-18)
 //   k_connect    one thread per light sample of the segment: builds the shadow
@@ -873,7 +877,7 @@ __global__ __launch_bounds__(BLOCK) void k_hit_records(RenderParams rp, DevScene
         if (ref >= 0) {
             const float4 o4 = ps.o_seed[pix], d4 = ps.d_depth[pix];
             const float4* q = sc.tri_q + 3 * (size_t)ref;
-            const Cand c = tri_candidate(q[0], q[1], q[2], mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z));
+            const Cand c = tri_candidate(q[0], q[1], q[2], mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), 0.f, PT_RAY_MAX);
             rec.u = c.u;
             rec.v = c.v;
             rec.prim = sc.tri_prim[ref];
@@ -905,8 +909,7 @@ static void trav_geometry(uint64_t n, uint32_t resident_waves, uint32_t tune_chu
     blocks = (uint32_t)std::min<uint64_t>((waves + 3) / 4, std::max<uint32_t>(resident_waves / 4u, 1u));
 }
 
-void wf_extend(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, uint32_t count, uint32_t* hit_queue,
-               uint32_t* hit_count, uint32_t* work_counter, uint32_t resident_waves, bool coherent, bool count_trav,
+void wf_extend(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, uint32_t count, uint32_t* work_counter, uint32_t resident_waves, bool coherent, bool count_trav,
                unsigned long long* trav_counters) {
     if (count == 0) return;
     uint32_t blocks, wave_chunk;
@@ -924,8 +927,12 @@ void wf_extend(hipStream_t s, const RenderParams& rp, const DevScene& sc, const 
         hipLaunchKernelGGL(k_extend<true>, dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, queue, count, work_counter, wave_chunk, trav_counters);
     else
         hipLaunchKernelGGL(k_extend<false>, dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, queue, count, work_counter, wave_chunk, trav_counters);
-    if (hit_queue)
-        hipLaunchKernelGGL(k_compact_hits, dim3(blocks_for(count, GEN_BLOCK)), dim3(GEN_BLOCK), 0, s, rp, ps, queue, count, hit_queue, hit_count);
+}
+
+// Queue of the paths whose extension ray hit something; misses end there.
+void wf_compact_hits(hipStream_t s, const RenderParams& rp, const PathState& ps, const uint32_t* queue, uint32_t count, uint32_t* hit_queue, uint32_t* hit_count) {
+    if (count == 0) return;
+    hipLaunchKernelGGL(k_compact_hits, dim3(blocks_for(count, GEN_BLOCK)), dim3(GEN_BLOCK), 0, s, rp, ps, queue, count, hit_queue, hit_count);
 }
 
 // `count_ptr` (device) holds the number of queued paths; `max_count` bounds it and sizes the grid.
