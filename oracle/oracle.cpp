@@ -56,6 +56,33 @@ inline F3 normalize(F3 v) {
 }
 inline F3 reflect(F3 i, F3 n) { return i - 2.0f * n * dot(n, i); }
 inline F3 lerp(F3 a, F3 b, float t) { return a + t * (b - a); }
+// OptiX SDK 6.x optixu_math_namespace.h `refract(r, i, n, ior)` (third-party header, not in
+// the reference tree; restated from its published definition): n is flipped and ior used
+// as eta when i leaves through n, 1/ior otherwise; false = total internal reflection.
+inline bool refract(F3& r, F3 i, F3 n, float ior) {
+    F3 nn = n;
+    float negNdotV = dot(i, nn);
+    float eta;
+    if (negNdotV > 0.0f) {
+        eta = ior;
+        nn = -n;
+        negNdotV = -negNdotV;
+    } else {
+        eta = 1.f / ior;
+    }
+    const float k = 1.f - eta * eta * (1.f - negNdotV * negNdotV);
+    if (k < 0.0f) {
+        r = f3(0.f);
+        return false;
+    }
+    r = normalize(eta * i - (eta * negNdotV + sqrtf(k)) * nn);
+    return true;
+}
+// same header: fresnel_schlick(cos_theta, exponent = 5, minimum = 0, maximum = 1)
+inline float fresnel_schlick(float cos_theta) {
+    const float v = 0.0f + (1.0f - 0.0f) * powf(fmaxf(0.0f, 1.0f - cos_theta), 5.0f);
+    return fminf(fmaxf(v, 0.0f), 1.0f);
+}
 
 const float PIf = 3.14159265358979323846f;
 const float RAY_MAX = 1e27f;  // RT_DEFAULT_MAX
@@ -786,8 +813,37 @@ void pathTracer2(const Ctx& c, const Attributes& attrib, Payload& payload) {
     payload.depth++;
 }
 
-// RayTracer.cu:496-963, DIFFUSE materials (GLASS / VOLUMETRIC branches are not
-// restated yet; orc_render rejects scenes that use them with this integrator).
+// RayTracer.cu:327-332
+inline float phaseHG(float wi_dot_wo, float g) {
+    float numerator = (1.0f - (g * g));
+    float denom = powf((1.0f + powf(g, 2.0f) + (2.0f * g * wi_dot_wo)), (3.0f / 2.0f));
+    return (1.0f / (4.0f * PIf)) * (numerator / denom);
+}
+
+// RayTracer.cu:337-360.  `wi` is taken by value there (and the only caller passes a
+// throw-away vector), so the sampled direction never leaves the function under either
+// semantics; only the phase-function value does.
+inline float samplePhaseHG(int semantics, F3 wo, F3 wi, float g, const float rando_samples[]) {
+    float cos_theta = .0f;
+    if (fabsf(g) < 0.001f) {
+        cos_theta = 1.0f - (2.0f * rando_samples[0]);
+    } else {
+        cos_theta = (1.0f / (2.0f * g)) * (1.0f + powf(g, 2.0f) - powf((1 - g * g) / (1 - g + (2.0f * g * rando_samples[0])), 2.0f));
+    }
+    float sin_theta = sqrtf(fmaxf(0.f, 1.0f - (cos_theta * cos_theta)));
+    (void)sin_theta;
+    float phi = 2.0f * PIf * rando_samples[1];
+    F3 v1 = f3(.0f), v2 = f3(.0f);
+    genCoordFrame(semantics, wo, v1, v2);
+    wi = sphericalDir(acosf(cos_theta), phi, v1, v2, wo);
+    (void)wi;
+    return phaseHG(-cos_theta, g);
+}
+
+// RayTracer.cu:362-365
+inline float computeTransmittance(float sigma_t, float param_dist_t, float ray_length) { return expf(-sigma_t * fminf(param_dist_t, RAY_MAX) * ray_length); }
+
+// RayTracer.cu:496-963, all three material types.
 void pathTracer(const Ctx& c, const Attributes& attrib, Payload& payload) {
     const OrcScene& s = *c.w->s;
     const int sem = c.w->o->semantics;
@@ -808,6 +864,8 @@ void pathTracer(const Ctx& c, const Attributes& attrib, Payload& payload) {
     F3 w_i = f3(.0f);
     F3 addon_throughput = f3(1.0f);
     F3 sampled_result = f3(1.0f);
+    F3 new_pos = f3(.0f);  // :517
+    float transmit = .0f;
     float pdf_NEE = .0f;
 
     if (cf.next_event_est && attrib.objType == PTC_LIGHT && payload.depth != 0) {  // :528-533
@@ -839,7 +897,59 @@ void pathTracer(const Ctx& c, const Attributes& attrib, Payload& payload) {
     float rand_vals[3] = {zeta_0, zeta_1, zeta_2};
     computePolarAngles(sem, s.sampling_method, phi, theta, rand_vals, t, mv.shininess);  // :566
 
-    if (mv.brdf_type == PTC_MOD_PHONG) {  // :675-684
+    if (mv.matType == PTC_GLASS) {  // :574-621
+        F3 inc_ray_dir = -attrib.wo;
+        F3 norm = n;
+        float n1 = 1.0f;
+        float n2 = mv.ior;
+        float eta = .0f;
+        float i_dot_n = .0f;
+        float reflect_probability = .0f;
+        F3 chosen_ray_dir = f3(.0f);
+        if (dot(inc_ray_dir, norm) >= .0f) {
+            // swapValue(n1, n2) takes its arguments by value (:296-300): no effect as committed
+            if (sem == 1) {
+                float tmp = n1;
+                n1 = n2;
+                n2 = tmp;
+            }
+            i_dot_n = dot(inc_ray_dir, norm);
+        } else {
+            i_dot_n = dot(inc_ray_dir, -norm);
+        }
+        eta = n2 / n1;
+        if (refract(chosen_ray_dir, inc_ray_dir, norm, eta))
+            reflect_probability = fresnel_schlick(i_dot_n);
+        else
+            reflect_probability = 1.0f;
+        float rand_valz = rnd(payload.seed);  // :614, one more draw before the light samples
+        if (rand_valz < reflect_probability)
+            w_i = normalize(reflect(inc_ray_dir, norm));
+        else
+            w_i = normalize(chosen_ray_dir);
+    } else if (mv.matType == PTC_VOLUMETRIC) {  // :622-672
+        F3 inc_ray_dir = -attrib.wo;
+        F3 norm = n;
+        if (dot(inc_ray_dir, norm) >= .0f) {
+            w_i = payload.dir;
+        } else {
+            F3 surface_pt = attrib.intersection;
+            F3 curr_pt = attrib.prev_intersection;
+            float ray_distance = length(surface_pt - curr_pt);
+            float param_dist_t = 0.08f;
+            transmit = computeTransmittance(mv.sigma_t, param_dist_t, ray_distance);
+            F3 place_holder_vec = f3(.0f);
+            float weight = samplePhaseHG(sem, inc_ray_dir, place_holder_vec, mv.g, rand_vals);
+            addon_throughput *= transmit * weight;  // overwritten by every case of the switch below
+            if (param_dist_t < ray_distance) {
+                w_i = payload.dir;
+                new_pos = curr_pt + (w_i * param_dist_t);
+            } else {
+                w_i = payload.dir;
+                new_pos = surface_pt;
+            }
+        }
+    } else if (mv.brdf_type == PTC_MOD_PHONG) {  // :675-684
         w = ((zeta_0 <= t) && (s.sampling_method == PTC_BRDF_SAMPLING)) ? r : n;
         F3 u = f3(.0f);
         F3 v = f3(.0f);
@@ -974,10 +1084,13 @@ void pathTracer(const Ctx& c, const Attributes& attrib, Payload& payload) {
             addon_throughput *= thru_put_boost;
         }
     }
-    payload.throughput *= addon_throughput;  // :940
-    payload.origin = attrib.intersection;    // :954
-    payload.dir = w_i;                       // :956
-    payload.depth++;                         // :959-962 (the condition is a tautology)
+    if (mv.matType != PTC_GLASS) payload.throughput *= addon_throughput;  // :935-941 (glass: times 1)
+    if (mv.matType == PTC_VOLUMETRIC || mv.matType == PTC_GLASS)             // :943-957
+        payload.origin = new_pos;  // glass never assigns new_pos: the path continues from (0,0,0)
+    else
+        payload.origin = attrib.intersection;
+    payload.dir = w_i;
+    payload.depth++;  // :959-962 (the condition is a tautology)
 }
 
 // ------------------------------------------------------------ ray generation --
@@ -1031,6 +1144,12 @@ F3 generateRays(const Ctx& c, uint32_t x, uint32_t y, int j0, int j1) {
         do {
             payload.seed = o.seeding == 0 ? tea16(key0, i++) : tea16(key0, ((uint32_t)j << 12) | b);  // :56
             Ray r{origin, dir, cf.epsilon, RAY_MAX};
+            // The volumetric branch reads payload.dir (RayTracer.cu:633, 661).  From the second
+            // segment on that is this ray's direction (PinholeCamera.cu:65); for a camera ray
+            // the reference leaves it uninitialised / stale from the previous sample, so it is
+            // DEFINED here as the camera ray's direction.
+            payload.origin = origin;
+            payload.dir = dir;
             if (counted) c.cnt->ext++;
             Closest hit = traceClosest(w, r);
             if (hit.prim < 0) {  // Common.cu:13-18
@@ -1070,12 +1189,6 @@ int validate(const OrcScene* s, const OrcOptions* o) {
     if (!s || !o) { g_err = "null argument"; return PTC_ERR_INVALID; }
     if (s->integrator < 0 || s->integrator > 4) { g_err = "bad integrator"; return PTC_ERR_INTEGRATOR; }
     if (o->bounce_cap == 0 || o->bounce_cap > 4096) { g_err = "bounce_cap must be 1..4096"; return PTC_ERR_INVALID; }
-    if (s->integrator == ORC_PATHTRACER) {
-        for (uint64_t i = 0; i < s->n_tris; ++i)
-            if (s->tris[i].mv.matType != PTC_DIFFUSE) { g_err = "glass/volumetric materials are not restated"; return PTC_ERR_UNSUPPORTED; }
-        for (uint64_t i = 0; i < s->n_spheres; ++i)
-            if (s->spheres[i].mv.matType != PTC_DIFFUSE) { g_err = "glass/volumetric materials are not restated"; return PTC_ERR_UNSUPPORTED; }
-    }
     return PTC_OK;
 }
 
@@ -1119,6 +1232,16 @@ const char* orc_last_error(void) { return g_err.c_str(); }
 uint32_t orc_tea16(uint32_t v0, uint32_t v1) { return tea16(v0, v1); }
 uint32_t orc_lcg(uint32_t* state) { return lcg(*state); }
 float orc_rnd(uint32_t* state) { return rnd(*state); }
+
+int orc_refract(const float* i3, const float* n3, float ior, float* r3) {
+    F3 r;
+    const bool ok = refract(r, f3(i3[0], i3[1], i3[2]), f3(n3[0], n3[1], n3[2]), ior);
+    r3[0] = r.x; r3[1] = r.y; r3[2] = r.z;
+    return ok ? 1 : 0;
+}
+
+float orc_fresnel_schlick(float cos_theta) { return fresnel_schlick(cos_theta); }
+float orc_phase_hg(float wi_dot_wo, float g) { return phaseHG(wi_dot_wo, g); }
 
 void orc_mat4_inverse(const float* m16, float* out16) {
     M4 a;

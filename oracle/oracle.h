@@ -74,6 +74,10 @@ int orc_render(const OrcScene* s, const OrcOptions* o, float* sum_out, float* re
 uint32_t orc_tea16(uint32_t v0, uint32_t v1);
 uint32_t orc_lcg(uint32_t* state);
 float    orc_rnd(uint32_t* state);
+/* refract / fresnel_schlick of the OptiX vector header as restated; phaseHG of RayTracer.cu:327 */
+int      orc_refract(const float* i3, const float* n3, float ior, float* r3);
+float    orc_fresnel_schlick(float cos_theta);
+float    orc_phase_hg(float wi_dot_wo, float g);
 
 /* Renderer::getResult's float3 -> RGBA8 conversion (Renderer.cpp:79-101):
  * flip rows, clamp to [0,1], truncate v*255. */

@@ -60,6 +60,12 @@ def lib():
         l.orc_mat4_inverse.argtypes = [C.c_void_p, C.c_void_p]
         l.orc_mat4_inverse.restype = None
         l.orc_last_error.restype = C.c_char_p
+        l.orc_refract.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+        l.orc_refract.restype = C.c_int
+        l.orc_fresnel_schlick.argtypes = [C.c_float]
+        l.orc_fresnel_schlick.restype = C.c_float
+        l.orc_phase_hg.argtypes = [C.c_float, C.c_float]
+        l.orc_phase_hg.restype = C.c_float
         _lib = l
     return _lib
 
@@ -123,3 +129,12 @@ def to_rgba8(result: np.ndarray) -> np.ndarray:
     res = np.ascontiguousarray(result, dtype=np.float32)
     lib().orc_to_rgba8(res.ctypes.data, w, h, out.ctypes.data)
     return out
+
+
+def refract(i, n, ior):
+    """(ok, r) of the restated OptiX `refract(r, i, n, ior)`."""
+    i = np.ascontiguousarray(i, dtype=np.float32)
+    n = np.ascontiguousarray(n, dtype=np.float32)
+    r = np.zeros(3, dtype=np.float32)
+    ok = lib().orc_refract(i.ctypes.data, n.ctypes.data, ior, r.ctypes.data)
+    return bool(ok), r

@@ -258,8 +258,6 @@ int makeParams(ptc_context* ctx, int frame_id, uint32_t w, uint32_t h, RenderPar
     if (!ctx->have_cfg) return fail(ctx, PTC_ERR_INVALID, "ptc_set_config has not been called");
     if (ctx->integrator < 0) return fail(ctx, PTC_ERR_INVALID, "ptc_set_integrator has not been called");
     if (!ctx->built) return fail(ctx, PTC_ERR_NOT_BUILT, "ptc_build has not been called since the last geometry upload");
-    if (ctx->integrator == INT_PATHTRACER && ctx->non_diffuse)
-        return fail(ctx, PTC_ERR_UNSUPPORTED, "glass / volumetric materials are outside the built path (pathtracer integrator)");
     std::memset(&rp, 0, sizeof(rp));
     rp.cf = ctx->cfg;
     rp.cf.next_event_est = ctx->next_event_est;

@@ -62,6 +62,32 @@ PT_HD vec3 cross(vec3 a, vec3 b) {
 PT_HD float length(vec3 v) { return sqrtf(dot(v, v)); }
 PT_HD vec3 normalize(vec3 v) { float inv = 1.0f / sqrtf(dot(v, v)); return v * inv; }
 PT_HD vec3 reflect(vec3 i, vec3 n) { return i - 2.0f * n * dot(n, i); }
+// refract(r, i, n, ior) of the OptiX 6.x vector header: n is flipped and `ior` used as eta
+// when i leaves through n, 1/ior otherwise; false (r = 0) on total internal reflection.
+PT_HD bool refract(vec3& r, vec3 i, vec3 n, float ior) {
+    vec3 nn = n;
+    float negNdotV = dot(i, nn);
+    float eta;
+    if (negNdotV > 0.0f) {
+        eta = ior;
+        nn = -n;
+        negNdotV = -negNdotV;
+    } else {
+        eta = 1.f / ior;
+    }
+    const float k = 1.f - eta * eta * (1.f - negNdotV * negNdotV);
+    if (k < 0.0f) {
+        r = mk3(0.f);
+        return false;
+    }
+    r = normalize(eta * i - (eta * negNdotV + sqrtf(k)) * nn);
+    return true;
+}
+// fresnel_schlick(cos_theta, exponent 5, minimum 0, maximum 1) of the same header
+PT_HD float fresnel_schlick(float cos_theta) {
+    const float v = 0.0f + (1.0f - 0.0f) * powf(fmaxf(0.0f, 1.0f - cos_theta), 5.0f);
+    return fminf(fmaxf(v, 0.0f), 1.0f);
+}
 PT_HD vec3 lerp3(vec3 a, vec3 b, float t) { return a + t * (b - a); }
 
 // Row-major 4x4 matrix; element (r,c) at m[r*4+c].

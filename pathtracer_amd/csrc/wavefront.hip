@@ -372,7 +372,8 @@ __global__ __launch_bounds__(BLOCK) void k_connect(RenderParams rp, DevScene sc,
                 qf.ab = b - qf.a;
                 qf.ac = c - qf.a;
                 // random numbers of this sample: position in the segment's LCG stream
-                const uint32_t lead = INTEG == INT_PATHTRACER ? 3u : 0u;  // zeta_0..2 come first (:537-539)
+                // zeta_0..2 come first (:537-539), a glass hit draws once more (:614)
+                const uint32_t lead = INTEG == INT_PATHTRACER ? (mv.matType == PTC_GLASS ? 4u : 3u) : 0u;
                 uint32_t st = lcg_skip(seed, lead + 2u * q);
                 const float u1 = rnd(st);
                 const float u2 = rnd(st);
@@ -653,7 +654,23 @@ __device__ __forceinline__ vec3 shade_pathtracer2(const RenderParams& rp, const 
     return radiance;
 }
 
-// RayTracer.cu:496-963 for DIFFUSE materials.
+// RayTracer.cu:327-332
+__device__ __forceinline__ float phase_hg(float wi_dot_wo, float g) {
+    const float numerator = (1.0f - (g * g));
+    const float denom = powf((1.0f + powf(g, 2.0f) + (2.0f * g * wi_dot_wo)), (3.0f / 2.0f));
+    return (1.0f / (4.0f * PT_PIf)) * (numerator / denom);
+}
+
+// RayTracer.cu:337-360: the sampled direction is written to a by-value argument and
+// never leaves the function, so only the phase-function value is computed here.
+__device__ __forceinline__ float sample_phase_hg(float g, float zeta) {
+    float cos_theta;
+    if (fabsf(g) < 0.001f) cos_theta = 1.0f - (2.0f * zeta);
+    else cos_theta = (1.0f / (2.0f * g)) * (1.0f + powf(g, 2.0f) - powf((1 - g * g) / (1 - g + (2.0f * g * zeta)), 2.0f));
+    return phase_hg(-cos_theta, g);
+}
+
+// RayTracer.cu:496-963, all three material types.
 __device__ __forceinline__ vec3 shade_pathtracer(const RenderParams& rp, const DevScene& sc, const PathState& ps, uint32_t p, const HitAttr& at, Segment& sg) {
     const PtcMaterialValue& mv = material_of(sc, at.mat);
     const PtcConfig& cf = rp.cf;
@@ -666,6 +683,7 @@ __device__ __forceinline__ vec3 shade_pathtracer(const RenderParams& rp, const D
     const float exp_beta = 2.0f;
     vec3 w_i = mk3(.0f);
     vec3 addon_throughput = mk3(1.0f);
+    vec3 new_pos = mk3(.0f);  // :517
 
     if (cf.next_event_est && is_light(at.mat) && sg.depth != 0u) {  // :528-533
         sg.depth = rp.max_depth_eff;
@@ -686,7 +704,43 @@ __device__ __forceinline__ vec3 shade_pathtracer(const RenderParams& rp, const D
     }
     compute_polar_angles(rp.semantics, rp.sampling_method, phi, theta, zeta_0, zeta_1, zeta_2, t, mv.shininess);  // :566
 
-    if (mv.brdf_type == PTC_MOD_PHONG) {  // :675-684
+    if (mv.matType == PTC_GLASS) {  // :574-621
+        const vec3 inc_ray_dir = -at.wo;
+        const vec3 norm = n;
+        float n1 = 1.0f, n2 = mv.ior;
+        float i_dot_n;
+        vec3 chosen_ray_dir = mk3(.0f);
+        if (dot(inc_ray_dir, norm) >= .0f) {
+            if (rp.semantics == 1) {  // swapValue takes its arguments by value (:296-300)
+                const float tmp = n1;
+                n1 = n2;
+                n2 = tmp;
+            }
+            i_dot_n = dot(inc_ray_dir, norm);
+        } else {
+            i_dot_n = dot(inc_ray_dir, -norm);
+        }
+        const float eta = n2 / n1;
+        float reflect_probability = 1.0f;
+        if (refract(chosen_ray_dir, inc_ray_dir, norm, eta)) reflect_probability = fresnel_schlick(i_dot_n);
+        const float rand_valz = rnd(st);  // :614, one more draw before the light samples
+        if (rand_valz < reflect_probability) w_i = normalize(reflect(inc_ray_dir, norm));
+        else w_i = normalize(chosen_ray_dir);
+    } else if (mv.matType == PTC_VOLUMETRIC) {  // :622-672
+        // payload.dir there is this segment's ray direction (PinholeCamera.cu:65; for a
+        // camera ray, where the reference leaves it unset, it is defined the same way)
+        const vec3 inc_ray_dir = -at.wo;
+        w_i = sg.d;
+        if (!(dot(inc_ray_dir, n) >= .0f)) {
+            const vec3 surface_pt = at.P, curr_pt = sg.o;
+            const float ray_distance = length(surface_pt - curr_pt);
+            const float param_dist_t = 0.08f;
+            const float transmit = expf(-mv.sigma_t * fminf(param_dist_t, PT_RAY_MAX) * ray_distance);  // :362-365
+            const float weight = sample_phase_hg(mv.g, zeta_0);
+            addon_throughput *= transmit * weight;  // every case of the switch below overwrites it
+            new_pos = param_dist_t < ray_distance ? curr_pt + (w_i * param_dist_t) : surface_pt;
+        }
+    } else if (mv.brdf_type == PTC_MOD_PHONG) {  // :675-684
         const vec3 w = ((zeta_0 <= t) && (rp.sampling_method == PTC_BRDF_SAMPLING)) ? r : n;
         vec3 u = mk3(.0f), v = mk3(.0f);
         gen_coord_frame(rp.semantics, w, u, v);
@@ -767,10 +821,11 @@ __device__ __forceinline__ vec3 shade_pathtracer(const RenderParams& rp, const D
         if (rnd(st) < q) addon_throughput *= mk3(.0f);
         else addon_throughput *= (1.0f / (1.0f - q));
     }
-    sg.thr *= addon_throughput;  // :940
-    sg.o = at.P;                 // :954
-    sg.d = w_i;                  // :956
-    sg.depth++;                  // :959-962 (the condition there is a tautology)
+    if (mv.matType != PTC_GLASS) sg.thr *= addon_throughput;  // :935-941 (glass: times 1)
+    // :943-957; glass never assigns new_pos, so its path continues from (0,0,0)
+    sg.o = (mv.matType == PTC_GLASS || mv.matType == PTC_VOLUMETRIC) ? new_pos : at.P;
+    sg.d = w_i;
+    sg.depth++;  // :959-962 (the condition there is a tautology)
     return radiance;
 }
 

@@ -171,7 +171,80 @@ def test_analytic_direct_needs_lightsamples_zero():
     assert floor.any() and (b[floor] != 0).any()
 
 
-def test_glass_is_rejected():
-    scene = SceneLoader().loadText(override_scene_text(scene_text("scene4/cornellRefract.test"), size="16 16", spp="1"))
-    with pytest.raises(RuntimeError, match="not restated"):
-        orc.render(scene)
+def _variant(rel, material, **over):
+    """Scene text with every `materialtype` command replaced by `materialtype <material>`."""
+    import re
+    t = re.sub(r"(?m)^materialtype .*$", "materialtype " + material, scene_text(rel))
+    return SceneLoader().loadText(override_scene_text(t, **over))
+
+
+def test_refract_and_fresnel_known_answers():
+    """Snell's law / Schlick's polynomial, the definitions the restated OptiX helpers follow."""
+    ok, r = orc.refract([0, 0, -1], [0, 0, 1], 1.5)          # normal incidence: straight through
+    assert ok and np.allclose(r, [0, 0, -1])
+    s45 = np.float32(np.sqrt(0.5))
+    ok, r = orc.refract([s45, 0, -s45], [0, 0, 1], 1.5)       # entering: sin(t) = sin(i) / 1.5
+    assert ok and np.isclose(r[0], s45 / 1.5, atol=1e-6) and r[2] < 0 and np.isclose(np.linalg.norm(r), 1, atol=1e-6)
+    ok, r = orc.refract([s45, 0, s45], [0, 0, 1], 1.5)        # leaving the denser side at 45 deg: total internal reflection
+    assert not ok and not r.any()
+    ok, r = orc.refract([0.1, 0, np.sqrt(1 - 0.01)], [0, 0, 1], 1.5)  # leaving, below the critical angle: sin(t) = 1.5 sin(i)
+    assert ok and np.isclose(r[0], 0.15, atol=1e-6) and r[2] > 0
+    f = orc.lib().orc_fresnel_schlick
+    assert f(1.0) == 0.0 and f(0.0) == 1.0 and f(-3.0) == 1.0 and np.isclose(f(0.5), 0.5 ** 5)
+    hg = orc.lib().orc_phase_hg
+    assert np.isclose(hg(0.3, 0.0), 1 / (4 * np.pi))          # isotropic
+    assert hg(-1.0, 0.7) > hg(1.0, 0.7)                       # the reference's sign convention: peak at wi.wo = -1
+
+
+def test_glass_first_segment():
+    """One segment per path (maxdepth 1): a glass hit shades like the same material without
+    the glass flag, except that it draws one more random number before the light samples
+    (RayTracer.cu:614) -- so only pixels whose camera ray hits glass may differ."""
+    over = dict(size="48 48", spp="1", maxdepth="1")
+    glass = _variant("scene4/cornellRefract.test", "glass", **over)
+    plain = _variant("scene4/cornellRefract.test", "diffuse", **over)
+    hits = orc.primary_hits(glass)["prim"].reshape(48, 48)
+    on_sphere = hits >= len(glass.triangles)
+    assert 50 < on_sphere.sum() < 48 * 48 / 2
+    for sem in (0, 1):
+        a, _, _ = orc.render(glass, semantics=sem, seeding=1)
+        b, _, _ = orc.render(plain, semantics=sem, seeding=1)
+        differs = (a.view(np.uint32) != b.view(np.uint32)).any(axis=2)
+        assert not differs[~on_sphere].any()
+        assert differs[on_sphere].mean() > 0.5
+
+
+def test_glass_continues_from_the_origin_with_unchanged_throughput():
+    """As committed, a glass hit leaves the throughput alone and restarts the path at (0,0,0)
+    (RayTracer.cu:517, 935-952).  In cornellRefract the point (0,0,0) lies in the floor plane,
+    so the longer path can only add light, and it stays finite."""
+    over = dict(size="48 48", spp="1")  # one sample: the pixel-centre ray the hit mask is made of
+    glass = _variant("scene4/cornellRefract.test", "glass", **over)
+    hits = orc.primary_hits(glass)["prim"].reshape(48, 48)
+    on_sphere = hits >= len(glass.triangles)
+    one, _, s1 = orc.render(_variant("scene4/cornellRefract.test", "glass", maxdepth="1", **over), semantics=1, seeding=1)
+    many, _, s2 = orc.render(glass, semantics=1, seeding=1, bounce_cap=16)
+    assert np.isfinite(many).all()
+    assert s2.extension_rays > s1.extension_rays
+    assert (many[on_sphere] >= one[on_sphere]).all()
+
+
+def test_volume_hit_kills_the_throughput():
+    """A volumetric surface keeps the incoming direction (RayTracer.cu:661); with it the
+    cosine factor of every sampling method is 0, so nothing after the first hit contributes:
+    pixels that see the volume first get the same value at any depth, and with one segment
+    the whole image equals the plain-material one bit for bit."""
+    over = dict(size="48 48", spp="1")  # one sample: the pixel-centre ray the hit mask is made of
+    vol1 = _variant("scene4/cornellVolume.test", "volumetric", maxdepth="1", **over)
+    plain1 = _variant("scene4/cornellVolume.test", "diffuse", maxdepth="1", **over)
+    vol = _variant("scene4/cornellVolume.test", "volumetric", **over)
+    hits = orc.primary_hits(vol)["prim"].reshape(48, 48)
+    on_sphere = hits >= len(vol.triangles)
+    assert on_sphere.sum() > 30
+    for sem in (0, 1):
+        a, _, _ = orc.render(vol1, semantics=sem, seeding=1)
+        b, _, _ = orc.render(plain1, semantics=sem, seeding=1)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        for cull in (0, 1):
+            c, _, _ = orc.render(vol, semantics=sem, seeding=1, bounce_cap=6, cull_zero=cull)
+            assert np.array_equal(a[on_sphere], c[on_sphere])
