@@ -155,10 +155,12 @@ enum {
     /* Traversal scheduling knobs for experiments: bits 0..7 idle lanes of a wave that
      * trigger a refill (1..64); bits 8..11 extension rays, bits 12..15 shadow rays:
      * 0 = one ray per thread, 1 = refilling waves + while-while rounds, 2 = refilling
-     * waves + single steps, 3 = automatic (extension: 0 for camera rays, 1 for later
-     * bounces; shadow: 1);
+     * waves + single steps, 3 = 0 for camera rays and 1 for later bounces (shadow: 1),
+     * 4 = refilling waves with deferred primitive tests (leaf primitives go to a
+     * per-wave queue in LDS and are tested 64 at a time), 5 = 0 for camera rays and
+     * 4 for later bounces (extension rays only);
      * bits 16..31 queue entries a wave reserves per atomic (multiple of 64, 0 = auto).
-     * Default 0x1320. */
+     * Default 0x4518. */
     PTC_OPT_TUNE_TRAVERSAL = 9,
     /* Hierarchy builder used by the next ptc_build: 0 = LBVH (Karras radix tree over
      * Morton codes), 1 = PLOC (locally-ordered clustering, better trees; default). */

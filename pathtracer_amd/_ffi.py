@@ -129,7 +129,8 @@ def core_lib():
     missing library is an error."""
     global _core
     if _core is None:
-        path = os.path.join(LIB_DIR, "libptcore.so")
+        # PTCORE_LIB: another build of the same library (A/B measurements of compile-time knobs)
+        path = os.environ.get("PTCORE_LIB") or os.path.join(LIB_DIR, "libptcore.so")
         if not os.path.exists(path):
             raise RuntimeError(f"{path} is missing: the HIP extension has not been built "
                                "(python -c 'import __graft_entry__ as g; g.build()')")

@@ -220,16 +220,18 @@ __device__ __forceinline__ float safe_inv(float d) { return fabsf(d) > 1e-30f ? 
 
 #define REF_DONE REF_EMPTY_WORD
 
+template <int LDS_N = TRAV_LDS_STACK>
 __device__ __forceinline__ void trav_push(uint32_t* lds_stack, uint32_t* spill, int& sp, uint32_t v) {
-    if (sp < TRAV_LDS_STACK) lds_stack[sp * TRAV_BLOCK] = v;
-    else spill[sp - TRAV_LDS_STACK] = v;
+    if (sp < LDS_N) lds_stack[sp * TRAV_BLOCK] = v;
+    else spill[sp - LDS_N] = v;
     ++sp;
 }
 
+template <int LDS_N = TRAV_LDS_STACK>
 __device__ __forceinline__ uint32_t trav_pop(const uint32_t* lds_stack, const uint32_t* spill, int& sp) {
     if (sp == 0) return REF_DONE;
     --sp;
-    return sp < TRAV_LDS_STACK ? lds_stack[sp * TRAV_BLOCK] : spill[sp - TRAV_LDS_STACK];
+    return sp < LDS_N ? lds_stack[sp * TRAV_BLOCK] : spill[sp - LDS_N];
 }
 
 // A ray whose direction has a NaN component can never be accepted by either
@@ -253,15 +255,28 @@ __device__ __forceinline__ bool trav_init(const DevScene& sc, vec3 o, vec3 d, fl
     return !(dir_is_nan(d) || sc.n_nodes == 0);
 }
 
-// Visit one internal node: slab-test both child boxes against [tmin, lim], go to
-// the nearer hit child, push the farther one.
-template <bool COUNT>
-__device__ __forceinline__ uint32_t trav_node(const DevScene& sc, const TravRay& r, uint32_t cur, float lim, uint32_t* lds_stack, uint32_t* spill, int& sp,
-                                              TravCounters& cnt) {
+// The 64 bytes of an internal node.
+struct NodeData {
+    float4 a, b, c;
+    uint4 ch;
+};
+
+__device__ __forceinline__ NodeData node_fetch(const DevScene& sc, uint32_t cur) {
     const float4* n4 = reinterpret_cast<const float4*>(sc.nodes + REF_NODE(cur));
-    const float4 a = n4[0], b = n4[1], c = n4[2];
-    const uint4 ch = *reinterpret_cast<const uint4*>(n4 + 3);
-    if (COUNT) cnt.nodes++;
+    NodeData n;
+    n.a = n4[0];
+    n.b = n4[1];
+    n.c = n4[2];
+    n.ch = *reinterpret_cast<const uint4*>(n4 + 3);
+    return n;
+}
+
+// Slab-test both child boxes against [tmin, lim], go to the nearer hit child, push the
+// farther one.
+template <int LDS_N = TRAV_LDS_STACK>
+__device__ __forceinline__ uint32_t node_eval(const NodeData& nd, const TravRay& r, float lim, uint32_t* lds_stack, uint32_t* spill, int& sp) {
+    const float4 a = nd.a, b = nd.b, c = nd.c;
+    const uint4 ch = nd.ch;
     // child 0: lo=(a.x,a.y,a.z) hi=(a.w,b.x,b.y)
     float t0 = __builtin_fmaf(a.x, r.ix, r.nox), t1 = __builtin_fmaf(a.w, r.ix, r.nox);
     float n0 = fminf(t0, t1), f0 = fmaxf(t0, t1);
@@ -282,12 +297,20 @@ __device__ __forceinline__ uint32_t trav_node(const DevScene& sc, const TravRay&
     const bool h1 = (n1 <= f1) && (REF_KIND(ch.y) != REF_EMPTY);
     if (h0 && h1) {
         const bool swap = n1 < n0;
-        trav_push(lds_stack, spill, sp, swap ? ch.x : ch.y);
+        trav_push<LDS_N>(lds_stack, spill, sp, swap ? ch.x : ch.y);
         return swap ? ch.y : ch.x;
     }
     if (h0) return ch.x;
     if (h1) return ch.y;
-    return trav_pop(lds_stack, spill, sp);
+    return trav_pop<LDS_N>(lds_stack, spill, sp);
+}
+
+// Visit one internal node.
+template <bool COUNT, int LDS_N = TRAV_LDS_STACK>
+__device__ __forceinline__ uint32_t trav_node(const DevScene& sc, const TravRay& r, uint32_t cur, float lim, uint32_t* lds_stack, uint32_t* spill, int& sp,
+                                              TravCounters& cnt) {
+    if (COUNT) cnt.nodes++;
+    return node_eval<LDS_N>(node_fetch(sc, cur), r, lim, lds_stack, spill, sp);
 }
 
 // One single step (either one internal node or one leaf): the "if-if" schedule.

@@ -10,6 +10,9 @@
 //                rays: resident waves reserve spans of the queue from one global
 //                counter and lanes that finish pull the next ray of the span
 //   k_shadow_static / k_shadow  the same pair for any-hit shadow rays
+//   k_trace_deferred<ANY>  refilling waves whose lanes queue leaf primitives in
+//                LDS and test them 64 at a time (scattered extension rays and all
+//                shadow rays by default)
 //   k_compact_hits  queue of the paths that hit something; a miss ends the path
 //                with the background colour (Common.cu:13-18)
 //   k_connect    one thread per light sample of the segment: builds the shadow
@@ -254,6 +257,214 @@ __global__ __launch_bounds__(BLOCK) void k_shadow_static(RenderParams rp, DevSce
     if (COUNT) {
         atomicAdd(&trav_counters[2], (unsigned long long)cnt.nodes);
         atomicAdd(&trav_counters[3], (unsigned long long)cnt.prims);
+    }
+}
+
+// ---- traversal with deferred primitive tests --------------------------------
+// In the kernels above a lane that reaches a leaf tests its primitives while the
+// other lanes of the wave wait (and the other way round), so on scattered rays only
+// a quarter of the lanes does useful work in an average instruction.  Here a lane
+// never tests a primitive of its own ray: reaching a leaf it appends one item
+// (ray lane, primitive) per primitive to a queue of its WAVE in LDS, pops its stack
+// and goes on with the next node.  Whenever the queue holds 64 items the whole wave
+// tests 64 primitives, one per lane, against rays it reads from LDS.  Both phases
+// run with (nearly) all lanes busy.  The price: a ray's closest distance may lag a
+// step or two behind the leaves it has passed, which costs a few extra node visits,
+// never a wrong result (only exact primitive tests accept, and
+// the closest hit is the minimum of (t, primitive index) over all accepted tests, in
+// any order -- an LDS 64-bit atomic min).
+//   ANY = false: extension rays (closest hit -> hit_t / hit_ref)
+//   ANY = true : shadow rays (first accepted primitive zeroes the ray's term)
+#ifndef DQ_STACK
+#define DQ_STACK 12                         /* LDS stack entries per ray; deeper ones in scratch */
+#endif
+#define DQ_SPILL (TRAV_LDS_STACK + TRAV_SPILL_STACK - DQ_STACK)
+#define DQ_LEAF 4u                          /* primitives a lane queues per step */
+#define DQ_ITEMS (64 + 64 * DQ_LEAF)        /* < 64 left over + DQ_LEAF per lane */
+#define DQ_ITEM(lane, sphere, slot) (((lane) << 26) | ((sphere) ? 0x2000000u : 0u) | (slot))
+
+struct DeferredLds {
+    uint32_t stack[DQ_STACK * BLOCK];
+    float2 ray[3][BLOCK];                   // (o.x,o.y) (o.z,d.x) (d.y,d.z)
+    unsigned long long best[BLOCK];         // (bits of closest t) << 32 | global primitive index; ANY: bits of tmax << 32
+    int best_ref[BLOCK];                    // HIT_* of the closest hit; ANY: anything but HIT_MISS = occluded
+    uint32_t items[BLOCK / 64][DQ_ITEMS];
+};
+
+// Make the LDS writes of this wave's lanes visible to its other lanes.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// One queued primitive test.  `rt` = block-relative index of the ray's owner.
+template <bool ANY>
+__device__ __forceinline__ void deferred_item(const DevScene& sc, DeferredLds& L, uint32_t item, uint32_t wave_base, float tmin) {
+    const uint32_t rt = wave_base + (item >> 26), slot = item & 0x1FFFFFFu;
+    const bool sphere = (item & 0x2000000u) != 0u;
+    const float2 r0 = L.ray[0][rt], r1 = L.ray[1][rt], r2 = L.ray[2][rt];
+    const vec3 o = mk3(r0.x, r0.y, r1.x), d = mk3(r1.y, r2.x, r2.y);
+    if (ANY) {
+        if (L.best_ref[rt] != HIT_MISS) return;  // already occluded
+        const float tmax = u2f((uint32_t)(L.best[rt] >> 32));
+        const bool hit = sphere ? any_sphere(sc, slot, o, d, tmin, tmax) : any_tri(sc, slot, o, d, tmin, tmax);
+        if (hit) L.best_ref[rt] = 0;
+        return;
+    }
+    const float tmax = PT_RAY_MAX;
+    const float t_best = u2f((uint32_t)(L.best[rt] >> 32));
+    Cand c;
+    if (sphere) {
+        c = sphere_candidate(sc.spheres[slot], o, d, nullptr);
+    } else {
+        const float4* q = sc.tri_q + 3 * (size_t)slot;
+        c = tri_candidate(q[0], q[1], q[2], o, d, tmin, t_best);
+    }
+    if (!c.hit || !(c.t > tmin && c.t < tmax) || c.t > t_best) return;
+    const uint32_t prim = (uint32_t)(sphere ? sc.sph_prim[slot] : sc.tri_prim[slot]);
+    const unsigned long long key = ((unsigned long long)f2u(c.t) << 32) | prim;
+    atomicMin(&L.best[rt], key);
+    if (L.best[rt] == key) L.best_ref[rt] = sphere ? HIT_SPHERE(slot) : (int)slot;
+}
+
+#ifndef DQ_MIN_WAVES
+#define DQ_MIN_WAVES 6   /* waves per SIMD the register allocation aims at (LDS allows 6 blocks per CU) */
+#endif
+template <bool ANY, bool COUNT>
+__global__ __launch_bounds__(BLOCK, DQ_MIN_WAVES) void k_trace_deferred(RenderParams rp, DevScene sc, PathState ps, const uint32_t* __restrict__ queue,
+                                                          const uint32_t* __restrict__ count_ptr, uint32_t count_arg,
+                                                          uint32_t* __restrict__ work_counter, uint32_t wave_chunk,
+                                                          unsigned long long* __restrict__ trav_counters, unsigned long long* __restrict__ shadow_total) {
+    __shared__ DeferredLds L;
+    const uint32_t count = ANY ? *count_ptr : count_arg;
+    if (ANY && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(shadow_total, (unsigned long long)count);
+    const uint32_t tid = threadIdx.x, lane = __lane_id(), wave = tid >> 6, wave_base = wave << 6;
+    uint32_t* my_stack = L.stack + tid;
+    uint32_t* items = L.items[wave];
+    uint32_t spill[DQ_SPILL];
+    const size_t plane = (size_t)rp.samples_per_path * ps.capacity;
+    TravRay r;
+    ClosestHit unused;
+    TravCounters cnt = {0u, 0u};
+    int sp = 0;
+    uint32_t cur = REF_DONE, p = 0, qn = 0;  // qn: items queued (wave-uniform)
+    bool active = false;                     // this lane owns a ray
+    WaveWork w = {0u, 0u, false};
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (;;) {
+        // ---- retire finished rays, fetch new ones
+        const bool fin = active && cur == REF_DONE;
+        const uint32_t nfree = (uint32_t)__popcll(__ballot(!active || fin));
+        const bool more = !(w.drained && w.pos >= w.end);
+        if (nfree == 64u || (more && nfree >= rp.tune_refill)) {
+            // every queued test belongs to a ray that is still owned: run them all first
+            wave_lds_sync();
+            while (qn > 0u) {
+                const uint32_t n = qn < 64u ? qn : 64u;
+                if (lane < n) {
+                    if (COUNT) cnt.prims++;
+                    deferred_item<ANY>(sc, L, items[qn - n + lane], wave_base, rp.cf.epsilon);
+                }
+                qn -= n;
+                wave_lds_sync();
+            }
+            if (fin) {
+                if (ANY) {
+                    if (L.best_ref[tid] != HIT_MISS) {
+                        ps.contrib[p] = 0.f;
+                        ps.contrib[p + plane] = 0.f;
+                        ps.contrib[p + 2 * plane] = 0.f;
+                    }
+                } else {
+                    ps.hit_t[p] = u2f((uint32_t)(L.best[tid] >> 32));
+                    ps.hit_ref[p] = L.best_ref[tid];
+                }
+                active = false;
+            }
+            if (more) {
+                const uint32_t idx = wave_fetch(w, !active, work_counter, wave_chunk, count);
+                if (idx != 0xFFFFFFFFu) {
+                    float4 o4, d4;
+                    if (ANY) {
+                        o4 = ps.sh_o[idx];
+                        d4 = ps.sh_d[idx];
+                        p = f2u(d4.w);   // slot of the ray's term
+                        d4.w = o4.w;     // tmax
+                    } else {
+                        p = queue[idx];
+                        o4 = ps.o_seed[p];
+                        d4 = ps.d_depth[p];
+                        d4.w = PT_RAY_MAX;
+                    }
+                    o4.w = rp.cf.epsilon;
+                    active = trav_init(sc, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), o4.w, d4.w, r, sp, cur, unused);
+                    if (active) {
+                        L.ray[0][tid] = make_float2(o4.x, o4.y);
+                        L.ray[1][tid] = make_float2(o4.z, d4.x);
+                        L.ray[2][tid] = make_float2(d4.y, d4.z);
+                        L.best[tid] = ((unsigned long long)f2u(d4.w) << 32) | 0xFFFFFFFFull;
+                        L.best_ref[tid] = HIT_MISS;
+                    } else if (!ANY) {  // NaN direction or empty scene: a miss
+                        ps.hit_t[p] = d4.w;
+                        ps.hit_ref[p] = HIT_MISS;
+                    }
+                }
+            }
+            if (!__any(active)) {
+                if (w.drained && w.pos >= w.end) break;
+                continue;
+            }
+        }
+        // ---- this lane's node: start the fetch, ...
+        bool do_node = active && REF_KIND(cur) == REF_INTERNAL;
+        if (ANY && do_node && L.best_ref[tid] != HIT_MISS) {  // occluded meanwhile
+            cur = REF_DONE;
+            do_node = false;
+        }
+        NodeData nd;
+        if (do_node) nd = node_fetch(sc, cur);
+        // ---- ... run the full batches of queued tests while it is in flight, ...
+        if (qn >= 64u) {
+            wave_lds_sync();
+            do {
+                if (COUNT) cnt.prims++;
+                deferred_item<ANY>(sc, L, items[qn - 64u + lane], wave_base, rp.cf.epsilon);
+                qn -= 64u;
+            } while (qn >= 64u);
+            wave_lds_sync();
+        }
+        // ---- ... then descend (the closest distance includes the tests just made)
+        if (do_node) {
+            if (COUNT) cnt.nodes++;
+            const float lim = ANY ? r.tmax : u2f((uint32_t)(L.best[tid] >> 32));
+            cur = node_eval<DQ_STACK>(nd, r, lim, my_stack, spill, sp);
+        }
+        // ---- leaves: queue their primitives, carry on with the stack
+        const uint32_t kind = REF_KIND(cur);
+        const bool leaf = active && cur != REF_DONE && (kind == REF_TRI || kind == REF_SPHERE);
+        if (__any(leaf)) {
+            const uint32_t have = leaf ? REF_COUNT(cur) : 0u;
+            const uint32_t n = have < DQ_LEAF ? have : DQ_LEAF;  // 0..4
+            uint32_t pre = 0u, tot = 0u;
+#pragma unroll
+            for (uint32_t b = 0; b < 3u; ++b) {
+                const unsigned long long m = __ballot(((n >> b) & 1u) != 0u);
+                pre += (uint32_t)__popcll(m & lt_mask) << b;
+                tot += (uint32_t)__popcll(m) << b;
+            }
+            if (leaf) {
+                const uint32_t first = REF_FIRST(cur);
+                for (uint32_t k = 0; k < n; ++k) items[qn + pre + k] = DQ_ITEM(lane, kind == REF_SPHERE, first + k);
+                // a longer leaf keeps its remainder for the next step
+                cur = have > n ? MAKE_LEAF(kind, first + n, have - n) : trav_pop<DQ_STACK>(my_stack, spill, sp);
+            }
+            qn += tot;
+        }
+    }
+    if (COUNT) {
+        atomicAdd(&trav_counters[ANY ? 2 : 0], (unsigned long long)cnt.nodes);
+        atomicAdd(&trav_counters[ANY ? 3 : 1], (unsigned long long)cnt.prims);
     }
 }
 
@@ -964,16 +1175,39 @@ static void trav_geometry(uint64_t n, uint32_t resident_waves, uint32_t tune_chu
     blocks = (uint32_t)std::min<uint64_t>((waves + 3) / 4, std::max<uint32_t>(resident_waves / 4u, 1u));
 }
 
+// Resident waves of the deferred-test kernels (their LDS footprint differs from k_extend's).
+static uint32_t deferred_resident_waves() {
+    static uint32_t cache[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (cache[dev] == 0u) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_deferred<false, false>, BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 3;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        cache[dev] = (uint32_t)per_cu * (uint32_t)cus * (BLOCK / 64);
+    }
+    return cache[dev];
+}
+
+// The item word of the deferred-test kernels holds 25 bits of primitive slot.
+static bool deferred_fits(const DevScene& sc) { return sc.n_tris < (1u << 25) && sc.n_spheres < (1u << 25); }
+
 void wf_extend(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, uint32_t count, uint32_t* work_counter, uint32_t resident_waves, bool coherent, bool count_trav,
                unsigned long long* trav_counters) {
     if (count == 0) return;
     uint32_t blocks, wave_chunk;
-    trav_geometry(count, resident_waves, rp.tune_chunk, blocks, wave_chunk);
+    uint32_t mode = rp.tune_mode == 3 ? (coherent ? 0u : 1u) : rp.tune_mode == 5 ? (coherent ? 0u : 4u) : rp.tune_mode;
+    if (mode == 4 && !deferred_fits(sc)) mode = 1;
+    trav_geometry(count, mode == 4 ? deferred_resident_waves() : resident_waves, rp.tune_chunk, blocks, wave_chunk);
     // mode 3: camera rays arrive in 8x8 pixel bundles and finish together, one ray per
     // thread is fastest; scattered rays finish at very different times, refilling pays
-    const uint32_t mode = rp.tune_mode == 3 ? (coherent ? 0u : 1u) : rp.tune_mode;
+    // (mode 5: the same with deferred primitive tests for the scattered rays)
     if (rp.brute_force)
         hipLaunchKernelGGL(k_extend_brute, dim3(blocks_for(count)), dim3(BLOCK), 0, s, rp, sc, ps, queue, count);
+    else if (mode == 4 && count_trav)
+        hipLaunchKernelGGL((k_trace_deferred<false, true>), dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, queue, nullptr, count, work_counter, wave_chunk, trav_counters, nullptr);
+    else if (mode == 4)
+        hipLaunchKernelGGL((k_trace_deferred<false, false>), dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, queue, nullptr, count, work_counter, wave_chunk, trav_counters, nullptr);
     else if (mode == 0 && count_trav)
         hipLaunchKernelGGL(k_extend_static<true>, dim3(blocks_for(count)), dim3(BLOCK), 0, s, rp, sc, ps, queue, count, trav_counters);
     else if (mode == 0)
@@ -1009,12 +1243,17 @@ void wf_shadow(hipStream_t s, const RenderParams& rp, const DevScene& sc, const 
                uint32_t* work_counter, uint32_t resident_waves, bool count_trav, unsigned long long* trav_counters, unsigned long long* shadow_total) {
     if (max_rays == 0) return;
     uint32_t blocks, wave_chunk;
-    trav_geometry(max_rays, resident_waves, rp.tune_chunk, blocks, wave_chunk);
+    const uint32_t smode = (rp.tune_shadow == 4 && !deferred_fits(sc)) ? 1u : rp.tune_shadow;
+    trav_geometry(max_rays, smode == 4 ? deferred_resident_waves() : resident_waves, rp.tune_chunk, blocks, wave_chunk);
     if (rp.brute_force)
         hipLaunchKernelGGL(k_shadow_brute, dim3(blocks_for(max_rays)), dim3(BLOCK), 0, s, rp, sc, ps, count_ptr, shadow_total);
-    else if (rp.tune_shadow == 0 && count_trav)
+    else if (smode == 4 && count_trav)
+        hipLaunchKernelGGL((k_trace_deferred<true, true>), dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, nullptr, count_ptr, 0u, work_counter, wave_chunk, trav_counters, shadow_total);
+    else if (smode == 4)
+        hipLaunchKernelGGL((k_trace_deferred<true, false>), dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, nullptr, count_ptr, 0u, work_counter, wave_chunk, trav_counters, shadow_total);
+    else if (smode == 0 && count_trav)
         hipLaunchKernelGGL(k_shadow_static<true>, dim3(blocks_for(max_rays)), dim3(BLOCK), 0, s, rp, sc, ps, count_ptr, trav_counters, shadow_total);
-    else if (rp.tune_shadow == 0)
+    else if (smode == 0)
         hipLaunchKernelGGL(k_shadow_static<false>, dim3(blocks_for(max_rays)), dim3(BLOCK), 0, s, rp, sc, ps, count_ptr, trav_counters, shadow_total);
     else if (count_trav)
         hipLaunchKernelGGL(k_shadow<true>, dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, count_ptr, work_counter, wave_chunk, trav_counters, shadow_total);

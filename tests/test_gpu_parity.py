@@ -203,3 +203,34 @@ def test_bvh_builders_agree():
     for f in ("prim", "t", "u", "v"):
         assert np.array_equal(out[0][0][f].view(np.uint32), out[1][0][f].view(np.uint32))
     assert np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
+
+
+@pytest.mark.parametrize("tune", [0x0020, 0x1120, 0x2220, 0x4420, 0x4408, 0x4440, 0x1320])
+@pytest.mark.parametrize("rel,over", [("scene4/dragon.test", dict(size="160 120", spp="2")),
+                                      ("scene3/cornellRR.test", dict(size="96 96", spp="4")),
+                                      ("scene2/sphere.test", dict(size="160 120"))])
+def test_traversal_kernels_agree(rel, over, tune):
+    """Every traversal kernel / schedule (static, refilling rounds, refilling steps, deferred
+    primitive tests; several refill thresholds) finds the same hits: hit records and
+    radiance sums are bit-identical to brute force over all primitives."""
+    scene = load(rel, **over)
+    opts = {_ffi.OPT_SEMANTICS: 1, _ffi.OPT_SEEDING: 1, _ffi.OPT_BOUNCE_CAP: 6}
+    r = Renderer(scene, options={**opts, _ffi.OPT_TUNE_TRAVERSAL: tune})
+    hits = r.primary_hits()
+    r.run()
+    sums = r.sums()
+    r.close()
+    key = (rel, tuple(sorted(over.items())))
+    if key not in _BRUTE:
+        b = Renderer(scene, options={**opts, _ffi.OPT_BRUTE_FORCE: 1})
+        bh = b.primary_hits()
+        b.run()
+        _BRUTE[key] = (bh, b.sums())
+        b.close()
+    want_hits, want_sums = _BRUTE[key]
+    for f in ("prim", "t", "u", "v"):
+        assert np.array_equal(hits[f].view(np.uint32), want_hits[f].view(np.uint32)), f
+    assert np.array_equal(sums.view(np.uint32), want_sums.view(np.uint32))
+
+
+_BRUTE = {}

@@ -25,7 +25,12 @@ def main():
             name = r["Kernel_Name"]
             if "true>" in name:  # the counting variants run outside the timed region
                 continue
-            key = "extend" if "k_extend" in name else "shadow" if "k_shadow" in name else None
+            if "k_extend" in name or "k_trace_deferred<false" in name:
+                key = "extend"
+            elif "k_shadow" in name or "k_trace_deferred<true" in name:
+                key = "shadow"
+            else:
+                key = None
             if key and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
                 tot[key][r["Counter_Name"]] += float(r["Counter_Value"])
                 disp[key][r["Counter_Name"]].add(r["Dispatch_Id"])
