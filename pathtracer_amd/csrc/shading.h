@@ -15,35 +15,77 @@ __device__ __forceinline__ vec3 phong_brdf(vec3 wi, vec3 reflect_vec, float shin
     return (diffuse / PT_PIf) + (specular * ((shininess + 2.0f) / (2.0f * PT_PIf)) * powf(fmaxf(dot(reflect_vec, wi), .0f), shininess));
 }
 
+// The reference evaluates its GGX terms through chains of libm calls on an angle:
+// tanf(acosf(x))^2, powf(cosf(acosf(x)), 4), sinf/cosf(atanf(a)).  Written with the angle
+// eliminated these are a handful of multiplications instead of several hundred
+// instructions, and agree with the libm chains to a few ulp (the same size as the
+// differences between two libm implementations).  What the chains do beyond rounding
+// is kept: acosf(x) is NaN for |x| > 1, which normalised vectors reach by one ulp.
+__device__ __forceinline__ float tan2_of_cos(float x) {  // tanf(acosf(x))^2
+    if (!(fabsf(x) <= 1.0f)) return __builtin_nanf("");
+    return ((1.0f - x) * (1.0f + x)) / (x * x);
+}
+__device__ __forceinline__ float cos4_of_cos(float x) {  // powf(cosf(acosf(x)), 4)
+    if (!(fabsf(x) <= 1.0f)) return __builtin_nanf("");
+    const float x2 = x * x;
+    return x2 * x2;
+}
+
 // RayTracer.cu:265-285
 __device__ __forceinline__ vec3 ggx_brdf(vec3 wi, vec3 wo, vec3 n, float roughness, vec3 K_s) {
     float wi_dot_n_dir = dot(wi, n);
     float wo_dot_n_dir = dot(wo, n);
     float alpha = roughness;
     vec3 h = normalize(wi + wo);
-    float theta_h = acosf(dot(h, n));
-    float cos_theta_h_4 = powf(cosf(theta_h), 4.0f);
-    float alpha_tan_theta_h_sq = (alpha * alpha) + powf(tanf(theta_h), 2.0f);
-    float D = (alpha * alpha) / (PT_PIf * cos_theta_h_4 * powf(alpha_tan_theta_h_sq, 2.0f));
-    float G_1_wi = (wi_dot_n_dir > .0f) ? 2.0f / (1.0f + sqrtf(1.0f + (alpha * alpha) * powf(tanf(acosf(dot(wi, n))), 2.0f))) : .0f;
-    float G_1_wo = (wo_dot_n_dir > .0f) ? 2.0f / (1.0f + sqrtf(1.0f + (alpha * alpha) * powf(tanf(acosf(dot(wo, n))), 2.0f))) : .0f;
+    const float cos_h = dot(h, n);  // theta_h = acosf(cos_h)
+    float cos_theta_h_4 = cos4_of_cos(cos_h);
+    float alpha_tan_theta_h_sq = (alpha * alpha) + tan2_of_cos(cos_h);
+    float D = (alpha * alpha) / (PT_PIf * cos_theta_h_4 * (alpha_tan_theta_h_sq * alpha_tan_theta_h_sq));
+    float G_1_wi = (wi_dot_n_dir > .0f) ? 2.0f / (1.0f + sqrtf(1.0f + (alpha * alpha) * tan2_of_cos(wi_dot_n_dir))) : .0f;
+    float G_1_wo = (wo_dot_n_dir > .0f) ? 2.0f / (1.0f + sqrtf(1.0f + (alpha * alpha) * tan2_of_cos(wo_dot_n_dir))) : .0f;
     float G = G_1_wi * G_1_wo;
-    vec3 F = K_s + (mk3(1.0f) - K_s) * powf(1.0f - dot(wi, h), 5.0f);
+    const float om = 1.0f - dot(wi, h), om2 = om * om;
+    vec3 F = K_s + (mk3(1.0f) - K_s) * (om2 * om2 * om);  // powf(., 5.0f)
     return (F * G * D) / (4.0f * wi_dot_n_dir * wo_dot_n_dir);
 }
 
 // RayTracer.cu:287-294
 __device__ __forceinline__ float ggx_pdf(vec3 wi, vec3 n, vec3 half_angle_vec, float t_val, float roughness) {
     float alpha = roughness;
-    float theta_h = acosf(dot(half_angle_vec, n));
-    float alpha_tan_theta_h_sq = (alpha * alpha) + powf(tanf(theta_h), 2.0f);
-    float D = (alpha * alpha) / (PT_PIf * powf(cosf(theta_h), 4.0f) * powf(alpha_tan_theta_h_sq, 2.0f));
+    const float cos_h = dot(half_angle_vec, n);
+    float alpha_tan_theta_h_sq = (alpha * alpha) + tan2_of_cos(cos_h);
+    float D = (alpha * alpha) / (PT_PIf * cos4_of_cos(cos_h) * (alpha_tan_theta_h_sq * alpha_tan_theta_h_sq));
     return ((1.0f - t_val) * fmaxf(dot(n, wi), .0f) / PT_PIf) + ((t_val * D * dot(n, half_angle_vec)) / (4.0f * dot(half_angle_vec, wi)));
 }
 
+// A polar angle carried as its cosine and sine.
+struct PolarAngle {
+    float c, s;
+};
+__device__ __forceinline__ PolarAngle angle_zero() { return PolarAngle{1.0f, 0.0f}; }
+// theta = acosf(x), x in [0, 1]
+__device__ __forceinline__ PolarAngle angle_acos(float x) {
+    if (!(fabsf(x) <= 1.0f)) return PolarAngle{__builtin_nanf(""), __builtin_nanf("")};
+    return PolarAngle{x, sqrtf((1.0f - x) * (1.0f + x))};
+}
+// theta = atanf(a), a >= 0.  `libm_chain`: go through the angle like the source does.
+// Literal semantics need that: their GGX half vector is cos(theta) * n, renormalised, and
+// whether dot(h, n) then lands on 1 or on 1 + 1 ulp (NaN downstream) depends on the last
+// bit of that cosine.
+__device__ __forceinline__ PolarAngle angle_atan(float a, bool libm_chain) {
+    if (libm_chain) {
+        const float th = atanf(a);
+        return PolarAngle{cosf(th), sinf(th)};
+    }
+    const float c = 1.0f / sqrtf(1.0f + a * a);
+    return PolarAngle{c, a * c};
+}
+
 // RayTracer.cu:316-322
-__device__ __forceinline__ vec3 spherical_dir(float theta, float phi, vec3 u, vec3 v, vec3 w) {
-    vec3 s = mk3(cosf(phi) * sinf(theta), sinf(phi) * sinf(theta), cosf(theta));
+__device__ __forceinline__ vec3 spherical_dir(PolarAngle theta, float phi, vec3 u, vec3 v, vec3 w) {
+    float sp, cp;
+    sincosf(phi, &sp, &cp);
+    vec3 s = mk3(cp * theta.s, sp * theta.s, theta.c);
     return normalize((s.x * u + s.y * v + s.z * w));
 }
 
@@ -59,23 +101,23 @@ __device__ __forceinline__ void gen_coord_frame(int semantics, vec3 w, vec3& u, 
 }
 
 // RayTracer.cu:232-257 (by-value outputs under literal semantics).
-__device__ __forceinline__ void compute_polar_angles(int semantics, uint32_t sampling_method, float& phi, float& theta, float z0, float z1, float z2, float t, float shininess) {
+__device__ __forceinline__ void compute_polar_angles(int semantics, uint32_t sampling_method, float& phi, PolarAngle& theta, float z0, float z1, float z2, float t, float shininess) {
     if (semantics != 1) return;
     switch (sampling_method) {
         case PTC_HEMISPHERE_SAMPLING:
             phi = 2.0f * PT_PIf * z2;
-            theta = acosf(z1);
+            theta = angle_acos(z1);
             break;
         case PTC_COSINE_SAMPLING:
             phi = 2.0f * PT_PIf * z2;
-            theta = acosf(sqrtf(z1));
+            theta = angle_acos(sqrtf(z1));
             break;
         case PTC_BRDF_SAMPLING:
             phi = 2.0f * PT_PIf * z2;
             if (z0 > t)
-                theta = acosf(sqrtf(z1));
+                theta = angle_acos(sqrtf(z1));
             else
-                theta = acosf(powf(z1, (1.0f / (shininess + 1.0f))));
+                theta = angle_acos(powf(z1, (1.0f / (shininess + 1.0f))));
             break;
         default:
             break;

@@ -836,7 +836,8 @@ __device__ __forceinline__ vec3 shade_pathtracer2(const RenderParams& rp, const 
     }
     uint32_t st = lcg_skip(sg.seed, 2u * per_light * sc.n_qlights);
     const float zeta1 = rnd(st), zeta2 = rnd(st);
-    const float theta = acosf(zeta1), phi = 2.0f * PT_PIf * zeta2;
+    const PolarAngle theta = angle_acos(zeta1);
+    const float phi = 2.0f * PT_PIf * zeta2;
     const vec3 w = normalize(at.normal);
     vec3 a = mk3(0, 1, 0);
     if (1.0f - fabsf(dot(a, w)) <= 1.0f) a = mk3(1, 0, 0);
@@ -890,7 +891,8 @@ __device__ __forceinline__ vec3 shade_pathtracer(const RenderParams& rp, const D
     const vec3 n = normalize(at.normal);
     const vec3 L_e = P3v(mv.emission), K_s = P3v(mv.specular), K_d = P3v(mv.diffuse);
     const vec3 r = normalize(reflect(-at.wo, at.normal));
-    float theta = .0f, phi = .0f;
+    PolarAngle theta = angle_zero();
+    float phi = .0f;
     const float exp_beta = 2.0f;
     vec3 w_i = mk3(.0f);
     vec3 addon_throughput = mk3(1.0f);
@@ -957,7 +959,7 @@ __device__ __forceinline__ vec3 shade_pathtracer(const RenderParams& rp, const D
         gen_coord_frame(rp.semantics, w, u, v);
         w_i = spherical_dir(theta, phi, u, v, w);
     } else {  // :685-696
-        const float theta_h_sample = atanf((mv.roughness * sqrtf(zeta_1)) / sqrtf(1.0f - zeta_1));
+        const PolarAngle theta_h_sample = angle_atan((mv.roughness * sqrtf(zeta_1)) / sqrtf(1.0f - zeta_1), rp.semantics != 1);
         const float phi_h_sample = 2.0f * PT_PIf * zeta_2;
         vec3 u_h = mk3(.0f), v_h = mk3(.0f);
         gen_coord_frame(rp.semantics, n, u_h, v_h);

@@ -234,3 +234,42 @@ def test_traversal_kernels_agree(rel, over, tune):
 
 
 _BRUTE = {}
+
+
+# ---- the HIP path against the reference's own recorded images ---------------------
+def test_sphere_png_from_the_gpu():
+    """scene 2/sphere.test as shipped (640x480, `direct`, 25 stratified light samples): the
+    GPU result, through Renderer::getResult's float->byte conversion, against the image the
+    reference recorded -- byte-exact on > 99.8 % of the pixels, the rest one grey level."""
+    import os
+    from util import ROOT, read_png
+    scene = SceneLoader().load(os.path.join(ROOT, "scenes", "scene2", "sphere.test"))
+    r = Renderer(scene)
+    r.run()
+    mine = np.frombuffer(bytes(r.getResult()), dtype=np.uint8).reshape(480, 640, 4)[..., :3].astype(int)
+    r.close()
+    ref = read_png(os.path.join(ROOT, "tests", "golden", "ref_sphere.png"))[..., :3].astype(int)
+    d = np.abs(mine - ref).max(axis=2)
+    assert (d == 0).mean() > 0.998
+    assert (d <= 1).mean() > 0.9999
+
+
+@pytest.mark.parametrize("name,rel,tol", [("cornellRR", "scene3/cornellRR.test", 0.035), ("ggx", "scene4/ggx.test", 0.02)])
+def test_converged_images_match_the_reference(name, rel, tol):
+    """Full-size renders at the scene's own settings (`intended` semantics, reference
+    seeding) against the reference's images: relative RMSE of 16x16-pixel block means
+    <= tol (3.5 % / 2 %: the Monte-Carlo noise of two independent 64-spp renders), channel
+    means within 2 %."""
+    import os
+    from util import ROOT, read_png
+    scene = SceneLoader().load(os.path.join(ROOT, "scenes", rel))
+    r = Renderer(scene, options={_ffi.OPT_SEMANTICS: 1, _ffi.OPT_SEEDING: 0})
+    r.run()
+    mine = np.frombuffer(bytes(r.getResult()), dtype=np.uint8).reshape(scene.height, scene.width, 4)[..., :3].astype(np.float64)
+    r.close()
+    ref = read_png(os.path.join(ROOT, "tests", "golden", f"ref_{name}.png"))[..., :3].astype(np.float64)
+    assert mine.shape == ref.shape
+    bm, br = block_mean(mine, 16), block_mean(ref, 16)
+    relrmse = np.sqrt(((bm - br) ** 2).mean()) / br.mean()
+    assert relrmse < tol, relrmse
+    assert np.allclose(mine.mean(axis=(0, 1)), ref.mean(axis=(0, 1)), rtol=0.02)
