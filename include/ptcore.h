@@ -157,10 +157,10 @@ enum {
      * 0 = one ray per thread, 1 = refilling waves + while-while rounds, 2 = refilling
      * waves + single steps, 3 = 0 for camera rays and 1 for later bounces (shadow: 1),
      * 4 = refilling waves with deferred primitive tests (leaf primitives go to a
-     * per-wave queue in LDS and are tested 64 at a time), 5 = 0 for camera rays and
-     * 4 for later bounces (extension rays only);
+     * per-wave queue in LDS and are tested 64 at a time), 5 = automatic: 0 for camera
+     * rays and for hierarchies of at most 64 nodes, 4 otherwise;
      * bits 16..31 queue entries a wave reserves per atomic (multiple of 64, 0 = auto).
-     * Default 0x4518. */
+     * Default 0x5518. */
     PTC_OPT_TUNE_TRAVERSAL = 9,
     /* Hierarchy builder used by the next ptc_build: 0 = LBVH (Karras radix tree over
      * Morton codes), 1 = PLOC (locally-ordered clustering, better trees; default). */

@@ -82,7 +82,7 @@ struct ptc_context {
     uint32_t bounce_cap = 1024;
     uint64_t batch_paths = 64u << 20;
     int bvh_builder = 1;
-    uint32_t tune_refill = 24, tune_mode = 5, tune_shadow = 4, tune_chunk = 0;
+    uint32_t tune_refill = 24, tune_mode = 5, tune_shadow = 5, tune_chunk = 0;
 
     PtcStats stats{};
     std::vector<hipEvent_t> ev_pool;
@@ -281,7 +281,7 @@ int makeParams(ptc_context* ctx, int frame_id, uint32_t w, uint32_t h, RenderPar
     rp.tune_mode = ctx->tune_mode;
     // shadow rays end at very different times (any hit stops them): refilling waves pay off
     // once the tree is deep enough for that to matter
-    rp.tune_shadow = ctx->tune_shadow == 3 ? 1u : ctx->tune_shadow == 5 ? 4u : ctx->tune_shadow;
+    rp.tune_shadow = ctx->tune_shadow == 3 ? 1u : ctx->tune_shadow;
     rp.tune_chunk = ctx->tune_chunk;
     return PTC_OK;
 }

@@ -1191,6 +1191,8 @@ static uint32_t deferred_resident_waves() {
     return cache[dev];
 }
 
+#define TINY_BVH_NODES 64u
+
 // The item word of the deferred-test kernels holds 25 bits of primitive slot.
 static bool deferred_fits(const DevScene& sc) { return sc.n_tris < (1u << 25) && sc.n_spheres < (1u << 25); }
 
@@ -1198,7 +1200,9 @@ void wf_extend(hipStream_t s, const RenderParams& rp, const DevScene& sc, const 
                unsigned long long* trav_counters) {
     if (count == 0) return;
     uint32_t blocks, wave_chunk;
-    uint32_t mode = rp.tune_mode == 3 ? (coherent ? 0u : 1u) : rp.tune_mode == 5 ? (coherent ? 0u : 4u) : rp.tune_mode;
+    // mode 5 (default): static for camera rays and for scenes whose whole hierarchy is a
+    // handful of nodes (every ray does the same few steps), deferred tests otherwise
+    uint32_t mode = rp.tune_mode == 3 ? (coherent ? 0u : 1u) : rp.tune_mode == 5 ? ((coherent || sc.n_nodes <= TINY_BVH_NODES) ? 0u : 4u) : rp.tune_mode;
     if (mode == 4 && !deferred_fits(sc)) mode = 1;
     trav_geometry(count, mode == 4 ? deferred_resident_waves() : resident_waves, rp.tune_chunk, blocks, wave_chunk);
     // mode 3: camera rays arrive in 8x8 pixel bundles and finish together, one ray per
@@ -1245,7 +1249,8 @@ void wf_shadow(hipStream_t s, const RenderParams& rp, const DevScene& sc, const 
                uint32_t* work_counter, uint32_t resident_waves, bool count_trav, unsigned long long* trav_counters, unsigned long long* shadow_total) {
     if (max_rays == 0) return;
     uint32_t blocks, wave_chunk;
-    const uint32_t smode = (rp.tune_shadow == 4 && !deferred_fits(sc)) ? 1u : rp.tune_shadow;
+    uint32_t smode = rp.tune_shadow == 5 ? (sc.n_nodes <= TINY_BVH_NODES ? 0u : 4u) : rp.tune_shadow;
+    if (smode == 4 && !deferred_fits(sc)) smode = 1u;
     trav_geometry(max_rays, smode == 4 ? deferred_resident_waves() : resident_waves, rp.tune_chunk, blocks, wave_chunk);
     if (rp.brute_force)
         hipLaunchKernelGGL(k_shadow_brute, dim3(blocks_for(max_rays)), dim3(BLOCK), 0, s, rp, sc, ps, count_ptr, shadow_total);
