@@ -4,7 +4,7 @@
     python bench.py --gpus N --steps K --warmup W [--workload dragon|cornell|cornell_ggx]
 
 A step = one full render of the workload (every pixel x every sample) through the
-C ABI: generate -> (extend -> connect -> shadow -> shade)* -> accumulate, plus, for N > 1, one
+C ABI: generate -> (extend -> surface -> shadow -> gather)* -> accumulate, plus, for N > 1, one
 RCCL reduce of the pre-gamma radiance sums to rank 0 and the resolve there.  Inputs
 (scene, BVH) are resident in HBM before the timed region.  With N > 1 every rank
 renders its own `spp` samples of every pixel (global sample indices
@@ -170,7 +170,7 @@ def main():
             "bytes_per_ray": round(b_ext, 1), "nodes_per_ray": round(nodes_per_ray, 2), "prims_per_ray": round(prims_per_ray, 2),
             "avg_launch_ms": round(st.extend_ms / launches, 4), "launches": int(st.extend_launches),
             "rays_per_launch": round(st.extension_rays / launches, 1),
-            "kernel_ms": {"extend": round(st.extend_ms, 2), "connect+shadow": round(st.connect_ms, 2), "shade": round(st.shade_ms, 2), "other": round(st.other_ms, 2)},
+            "kernel_ms": {"extend": round(st.extend_ms, 2), "shadow": round(st.connect_ms, 2), "surface+gather": round(st.shade_ms, 2), "other": round(st.other_ms, 2)},
             "shadow": {"bytes_per_ray": round(b_sh, 1), "nodes_per_ray": round(snodes_per_ray, 2), "prims_per_ray": round(sprims_per_ray, 2),
                        "rays": int(st.shadow_rays)},
         }

@@ -102,8 +102,10 @@ typedef struct PtcStats {
     uint64_t paths;            /* camera paths started                         */
     uint64_t extension_rays;   /* radiance segments traced (paths x bounces)   */
     uint64_t shadow_rays;      /* shadow rays traced                           */
-    uint64_t extend_launches, connect_launches, shade_launches;
-    double   extend_ms, connect_ms, shade_ms, other_ms; /* HIP-event time, only with PTC_OPT_PROFILE */
+    uint64_t extend_launches, connect_launches, shade_launches; /* extension / shadow / surface launches */
+    /* HIP-event time, only with PTC_OPT_PROFILE: extension-ray traversal, shadow-ray
+     * traversal, surface + gather kernels, everything else */
+    double   extend_ms, connect_ms, shade_ms, other_ms;
     uint64_t nodes_visited, prims_tested;               /* extension rays, only with PTC_OPT_COUNT_TRAVERSAL */
     uint64_t shadow_nodes_visited, shadow_prims_tested; /* shadow rays, same option                          */
     uint32_t bvh_nodes, bvh_max_depth;

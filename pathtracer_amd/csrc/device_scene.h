@@ -113,6 +113,8 @@ struct PathState {
     float4* d_depth;   // direction.xyz, depth (bits)
     float4* thr;       // throughput.xyz, segment number within the path (bits)
     float4* L;         // radiance accumulated by this path
+    float4* g_a;       // segments waiting for their light terms: constant part, emission flag (bits)
+    float4* g_thr;     //   throughput before the segment
     float* hit_t;      // closest-hit distance of the current segment
     int32_t* hit_ref;  // see HIT_*
     float* contrib;    // 3 planes of [light sample][capacity]: per-shadow-sample f*G terms

@@ -72,6 +72,7 @@ struct ptc_context {
     uint32_t contrib_samples = 0;
     uint32_t* queue[2] = {nullptr, nullptr};    // live paths of this / the next bounce
     uint32_t* hitq = nullptr;                   // paths of this bounce that hit something
+    uint32_t* gatherq = nullptr;                // segments of this bounce whose radiance waits for the light terms
     uint32_t* qcount = nullptr;                 // two groups {hit, next, shadow, extend work, shadow work} used alternately, [16] generate
     uint32_t resident_waves = 6144;
     unsigned long long* counters = nullptr;     // [0..3] traversal nodes/prims (extension, shadow), [4] shadow rays
@@ -127,11 +128,11 @@ void freeTargets(ptc_context* c) {
 }
 
 void freePaths(ptc_context* c) {
-    for (void* p : {(void*)c->ps.o_seed, (void*)c->ps.d_depth, (void*)c->ps.thr, (void*)c->ps.L, (void*)c->ps.hit_t, (void*)c->ps.hit_ref,
-                    (void*)c->ps.contrib, (void*)c->ps.sh_o, (void*)c->ps.sh_d, (void*)c->queue[0], (void*)c->queue[1], (void*)c->hitq})
+    for (void* p : {(void*)c->ps.o_seed, (void*)c->ps.d_depth, (void*)c->ps.thr, (void*)c->ps.L, (void*)c->ps.g_a, (void*)c->ps.g_thr, (void*)c->ps.hit_t, (void*)c->ps.hit_ref,
+                    (void*)c->ps.contrib, (void*)c->ps.sh_o, (void*)c->ps.sh_d, (void*)c->queue[0], (void*)c->queue[1], (void*)c->hitq, (void*)c->gatherq})
         if (p) (void)hipFree(p);
     c->ps = PathState{};
-    c->queue[0] = c->queue[1] = c->hitq = nullptr;
+    c->queue[0] = c->queue[1] = c->hitq = c->gatherq = nullptr;
     c->contrib_samples = 0;
 }
 
@@ -168,6 +169,8 @@ int ensurePaths(ptc_context* ctx, uint32_t capacity, uint32_t contrib_samples) {
     CHK(hipMalloc((void**)&ctx->ps.d_depth, (size_t)capacity * sizeof(float4)));
     CHK(hipMalloc((void**)&ctx->ps.thr, (size_t)capacity * sizeof(float4)));
     CHK(hipMalloc((void**)&ctx->ps.L, (size_t)capacity * sizeof(float4)));
+    CHK(hipMalloc((void**)&ctx->ps.g_a, (size_t)capacity * sizeof(float4)));
+    CHK(hipMalloc((void**)&ctx->ps.g_thr, (size_t)capacity * sizeof(float4)));
     CHK(hipMalloc((void**)&ctx->ps.hit_t, (size_t)capacity * sizeof(float)));
     CHK(hipMalloc((void**)&ctx->ps.hit_ref, (size_t)capacity * sizeof(int32_t)));
     CHK(hipMalloc((void**)&ctx->ps.contrib, std::max<size_t>((size_t)capacity * contrib_samples * 3, 1) * sizeof(float)));
@@ -176,6 +179,7 @@ int ensurePaths(ptc_context* ctx, uint32_t capacity, uint32_t contrib_samples) {
     CHK(hipMalloc((void**)&ctx->queue[0], (size_t)capacity * sizeof(uint32_t)));
     CHK(hipMalloc((void**)&ctx->queue[1], (size_t)capacity * sizeof(uint32_t)));
     CHK(hipMalloc((void**)&ctx->hitq, (size_t)capacity * sizeof(uint32_t)));
+    CHK(hipMalloc((void**)&ctx->gatherq, (size_t)capacity * sizeof(uint32_t)));
     ctx->ps.capacity = capacity;
     ctx->contrib_samples = contrib_samples;
     return PTC_OK;
@@ -299,36 +303,41 @@ int uploadLights(ptc_context* ctx) {
 #define N_QCOUNT 20
 
 // Trace every bounce of the paths in queue[0] (count0 of them).  Per bounce:
-// extend + hit compaction, connect + shadow over the hit queue (queue lengths stay
-// on the device; the grids are sized by the bounce's path count), shade, survivors
-// -> next queue, whose length is the one word read back.
+// extend, hit compaction, surface (light samples + shadow rays, next direction,
+// survivors -> next queue), shadow, gather (radiance of the segments that sampled the lights).  Queue
+// lengths stay on the device; the grids are sized by the bounce's path count; the next
+// queue's length is the one word read back.
 int runBounces(ptc_context* ctx, const RenderParams& rp, const DevScene& sc, uint32_t count0, uint32_t sample_begin) {
     uint32_t count = count0;
     int cur = 0;
     uint32_t bounce = 0;
     const uint32_t S = rp.samples_per_path;
     while (count > 0) {
-        uint32_t* grp = ctx->qcount + 8 * (bounce & 1u);  // {hit count, next count, shadow-ray count, extend work, shadow work}
-        CHK(hipMemsetAsync(grp, 0, 5 * sizeof(uint32_t), ctx->stream));
+        uint32_t* grp = ctx->qcount + 8 * (bounce & 1u);  // {hit count, next count, shadow-ray count, extend work, shadow work, gather count}
+        CHK(hipMemsetAsync(grp, 0, 6 * sizeof(uint32_t), ctx->stream));
         {
             Timed t(ctx, 0);
             wf_extend(ctx->stream, rp, sc, ctx->ps, ctx->queue[cur], count, grp + 3, ctx->resident_waves, bounce == 0, ctx->count_trav != 0, ctx->counters);
         }
+        ctx->stats.extension_rays += count;
+        ctx->stats.extend_launches++;
         {
             Timed t(ctx, 3);
             wf_compact_hits(ctx->stream, rp, ctx->ps, ctx->queue[cur], count, ctx->hitq, grp);
         }
-        ctx->stats.extension_rays += count;
-        ctx->stats.extend_launches++;
-        if (S) {
-            Timed t(ctx, 1);
-            wf_connect(ctx->stream, rp, sc, ctx->ps, ctx->hitq, grp, count, S, grp + 2);
-            wf_shadow(ctx->stream, rp, sc, ctx->ps, grp + 2, (uint64_t)count * S, grp + 4, ctx->resident_waves, ctx->count_trav != 0, ctx->counters, ctx->counters + 4);
-            ctx->stats.connect_launches++;
-        }
         {
             Timed t(ctx, 2);
-            wf_shade(ctx->stream, rp, sc, ctx->ps, ctx->hitq, grp, count, ctx->npix_pad, sample_begin, ctx->segctr, ctx->queue[cur ^ 1], grp + 1);
+            wf_surface(ctx->stream, rp, sc, ctx->ps, ctx->hitq, grp, count, ctx->npix_pad, sample_begin, ctx->segctr, ctx->queue[cur ^ 1], grp + 1, ctx->gatherq,
+                       grp + 5, grp + 2);
+        }
+        if (S) {
+            {
+                Timed t(ctx, 1);
+                wf_shadow(ctx->stream, rp, sc, ctx->ps, grp + 2, (uint64_t)count * S, grp + 4, ctx->resident_waves, ctx->count_trav != 0, ctx->counters, ctx->counters + 4);
+            }
+            Timed t(ctx, 2);
+            wf_gather(ctx->stream, rp, sc, ctx->ps, ctx->gatherq, grp + 5, count);
+            ctx->stats.connect_launches++;
         }
         ctx->stats.shade_launches++;
         CHK(hipMemcpyAsync(ctx->h_count, grp + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));

@@ -9,21 +9,22 @@
 //                coherent camera rays; the refilling kernel serves scattered
 //                rays: resident waves reserve spans of the queue from one global
 //                counter and lanes that finish pull the next ray of the span
-//   k_shadow_static / k_shadow  the same pair for any-hit shadow rays
-//   k_trace_deferred<ANY>  refilling waves whose lanes queue leaf primitives in
-//                LDS and test them 64 at a time (scattered extension rays and all
-//                shadow rays by default)
-//   k_compact_hits  queue of the paths that hit something; a miss ends the path
-//                with the background colour (Common.cu:13-18)
-//   k_connect    one thread per light sample of the segment: builds the shadow
-//                ray and its f*G term; rays whose term is exactly 0 are dropped,
-//                the others are queued
-//   k_shadow     any-hit traversal of the queued shadow rays (rtTrace ray type 1,
-//                Common.cu:30-36); an occluded ray zeroes its term
-//   k_shade      the closest-hit program of the chosen integrator
-//                (RayTracer.cu) + the bounce-loop bookkeeping of
+//   k_trace_deferred<false>  refilling waves whose lanes queue leaf primitives in
+//                LDS and test them 64 at a time (scattered extension rays by default)
+//   k_surface    one thread per path after the extension: a miss ends the path
+//                with the background colour (Common.cu:13-18); at a hit, the part of
+//                the chosen integrator's closest-hit program (RayTracer.cu) that
+//                does not depend on shadow-ray visibility -- every light sample's
+//                shadow ray and f*G term (rays whose term is exactly 0 are dropped,
+//                the others queued), emission, the sampled direction, throughput,
+//                Russian roulette -- plus the bounce-loop bookkeeping of
 //                PinholeCamera.cu:54-66; survivors are compacted into the next
 //                queue (wave64 ballot + popcount prefix, one atomic per block)
+//   k_shadow_static / k_shadow / k_trace_deferred<true>
+//                any-hit traversal of the queued shadow rays (rtTrace ray type 1,
+//                Common.cu:30-36); an occluded ray zeroes its term
+//   k_gather     radiance of the segments that sampled the lights: folds the terms
+//                in the order the reference's loops add them
 //   k_accumulate per-pixel sum of the batch's samples, in sample order
 //   k_resolve    average, gamma, frame lerp (PinholeCamera.cu:70-80)
 //
@@ -56,18 +57,19 @@ __device__ __forceinline__ bool pixel_of(const RenderParams& rp, uint32_t pix, u
     return x < rp.width && y < rp.height;
 }
 
-// Append `value` for every thread with keep=true.  Wave64 ballot + popcount give
-// the position inside the wave, the waves' counts meet in LDS and ONE atomic per
-// block reserves the block's span (a per-wave atomic on the single counter word
-// saturates the atomic unit at these queue sizes).  Must be reached by every
-// thread of the block.
-__device__ __forceinline__ void queue_append(bool keep, uint32_t value, uint32_t* __restrict__ out, uint32_t* __restrict__ counter) {
+// Reserve one queue position for every thread with keep=true and return it.  Wave64
+// ballot + popcount give the position inside the wave, the waves' counts meet in LDS
+// and ONE atomic per block reserves the block's span (a per-wave atomic on the single
+// counter word saturates the atomic unit at these queue sizes).  Must be reached by
+// every thread of the block; may be called repeatedly.
+__device__ __forceinline__ uint32_t queue_reserve(bool keep, uint32_t* __restrict__ counter) {
     __shared__ uint32_t s_cnt[16];
     __shared__ uint32_t s_base;
     const unsigned long long mask = __ballot(keep);
     const uint32_t lane = __lane_id();
     const uint32_t wave = threadIdx.x >> 6, nwaves = (blockDim.x + 63u) >> 6;
     const uint32_t prefix = __popcll(mask & ((1ull << lane) - 1ull));
+    __syncthreads();  // the previous call's readers are done with s_cnt / s_base
     if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(mask);
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -78,7 +80,13 @@ __device__ __forceinline__ void queue_append(bool keep, uint32_t value, uint32_t
     __syncthreads();
     uint32_t base = s_base;
     for (uint32_t w = 0; w < wave; ++w) base += s_cnt[w];
-    if (keep) out[base + prefix] = value;
+    return base + prefix;
+}
+
+// Append `value` for every thread with keep=true.
+__device__ __forceinline__ void queue_append(bool keep, uint32_t value, uint32_t* __restrict__ out, uint32_t* __restrict__ counter) {
+    const uint32_t at = queue_reserve(keep, counter);
+    if (keep) out[at] = value;
 }
 
 __device__ __forceinline__ uint32_t segment_seed(const RenderParams& rp, uint32_t key0, uint32_t sample, uint32_t bounce, uint32_t* segctr, uint32_t pix) {
@@ -480,8 +488,8 @@ __global__ __launch_bounds__(BLOCK) void k_extend_brute(RenderParams rp, DevScen
     ps.hit_ref[p] = best.ref;
 }
 
-// Paths that hit something go to `hit_queue` (the only ones the connect and shade
-// kernels look at); a miss ends the path right here: radiance = background
+// Paths that hit something go to `hit_queue` (the only ones the surface kernel looks at,
+// so that its waves are full); a miss ends the path right here: radiance = background
 // colour, not scaled by the throughput (Common.cu:13-18).
 __global__ __launch_bounds__(GEN_BLOCK) void k_compact_hits(RenderParams rp, PathState ps, const uint32_t* __restrict__ queue, uint32_t count,
                                                         uint32_t* __restrict__ hit_queue, uint32_t* __restrict__ hit_count) {
@@ -502,7 +510,7 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_compact_hits(RenderParams rp, Pat
     queue_append(hit, p, hit_queue, hit_count);
 }
 
-// ----------------------------------------------------------------- connect --
+// ----------------------------------------------------------- light samples --
 // Material access helpers.
 __device__ __forceinline__ const PtcMaterialValue& material_of(const DevScene& sc, uint32_t mat) { return sc.materials[mat & ~MAT_LIGHT_BIT]; }
 __device__ __forceinline__ bool is_light(uint32_t mat) { return (mat & MAT_LIGHT_BIT) != 0u; }
@@ -511,156 +519,113 @@ __device__ __forceinline__ bool is_light(uint32_t mat) { return (mat & MAT_LIGHT
 // samples_per_path * capacity floats.
 __device__ __forceinline__ uint32_t contrib_slot(const PathState& ps, uint32_t p, uint32_t q) { return q * ps.capacity + p; }
 
-// One thread per (path with a hit, light sample).  Computes the shadow ray and the
-// term the reference adds when that ray is unoccluded (f_brdf*G for the quad-light
-// integrators, the Blinn-Phong term for `raytracer`).  A term that is exactly zero
-// adds nothing whether or not the ray is blocked, so no ray is queued for it; any
-// other value (NaN included) is stored and its ray queued; k_shadow zeroes the
-// term of an occluded ray.
+// Does the integrator sample the lights at this hit?
 template <int INTEG>
-__global__ __launch_bounds__(BLOCK) void k_connect(RenderParams rp, DevScene sc, PathState ps, const uint32_t* __restrict__ queue,
-                                                   const uint32_t* __restrict__ count_ptr, uint32_t n_samples, uint32_t* __restrict__ shadow_count) {
-    const uint32_t count = *count_ptr;  // hits of this bounce, written by k_compact_hits
-    const uint64_t tid = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    const bool valid = tid < (uint64_t)count * n_samples;
+__device__ __forceinline__ bool samples_lights(const RenderParams& rp, uint32_t mat, uint32_t depth) {
+    if (INTEG == INT_ANALYTICDIRECT) return false;
+    if (INTEG == INT_DIRECT) return !is_light(mat);                                             // RayTracer.cu:160-165
+    if (INTEG == INT_PATHTRACER) return !(rp.cf.next_event_est && is_light(mat) && depth != 0u);  // :528-533
+    if (INTEG == INT_PATHTRACER2) return !(depth > 0u && is_light(mat));                         // :436-441
+    return true;
+}
+
+// Light sample q of a segment: the shadow ray and the term the reference adds when that
+// ray is unoccluded (f_brdf*G for the quad-light integrators, the Blinn-Phong term for
+// `raytracer`).
+template <int INTEG>
+__device__ __forceinline__ vec3 light_sample(const RenderParams& rp, const DevScene& sc, const HitAttr& at, const PtcMaterialValue& mv, uint32_t seed, uint32_t q,
+                                             vec3& sh_o, vec3& sh_d, float& sh_tmax) {
+    const PtcConfig& cf = rp.cf;
     vec3 term = mk3(0.f);
-    vec3 sh_o = mk3(0.f), sh_d = mk3(0.f);
-    float sh_tmax = 0.f;
-    uint32_t slot = 0;
-    bool need_ray = false;
-    if (valid) {
-        const uint32_t i = (uint32_t)(tid % count), q = (uint32_t)(tid / count);
-        const uint32_t p = queue[i];
-        slot = contrib_slot(ps, p, q);
-        const float4 o4 = ps.o_seed[p], d4 = ps.d_depth[p];
-        const vec3 o = mk3(o4.x, o4.y, o4.z), d = mk3(d4.x, d4.y, d4.z);
-        const uint32_t seed = f2u(o4.w), depth = f2u(d4.w);
-        HitAttr at;
-        hit_attributes(sc, ps.hit_ref[p], ps.hit_t[p], o, d, at);
-        const PtcMaterialValue& mv = material_of(sc, at.mat);
-        const PtcConfig& cf = rp.cf;
-        bool skip = false;
-        if (INTEG == INT_DIRECT) skip = is_light(at.mat);                                           // RayTracer.cu:160-165
-        if (INTEG == INT_PATHTRACER) skip = cf.next_event_est && is_light(at.mat) && depth != 0u;  // :528-533
-        if (INTEG == INT_PATHTRACER2) skip = depth > 0u && is_light(at.mat);                       // :436-441
-        if (!skip) {
-            vec3 light_pos = mk3(0.f);
-            QuadFrame qf;
-            qf.a = qf.ab = qf.ac = mk3(0.f);
-            if (INTEG == INT_RAYTRACER) {
-                // RayTracer.cu:42-86: point lights, then directional lights
-                if (q < sc.n_plights) {
-                    const vec3 loc = P3v(sc.plights[q].location);
-                    sh_d = normalize(loc - at.P);
-                    sh_tmax = length(loc - at.P);
-                } else {
-                    sh_d = P3v(sc.dlights[q - sc.n_plights].direction);
-                    sh_tmax = PT_RAY_MAX;
-                }
-                sh_o = at.P + sh_d * cf.epsilon;
-                const vec3 H = normalize(sh_d + at.wo);
-                vec3 I = P3v(mv.diffuse) * fmaxf(dot(at.normal, sh_d), 0);
-                I += P3v(mv.specular) * powf(fmaxf(dot(at.normal, H), 0), mv.shininess);
-                if (q < sc.n_plights) {
-                    const float lightDist = sh_tmax;
-                    const float att = dot(P3v(sc.plights[q].attenuation), mk3(1, lightDist, lightDist * lightDist));
-                    I *= P3v(sc.plights[q].color) / att;
-                } else {
-                    I *= P3v(sc.dlights[q - sc.n_plights].color);
-                }
-                term = I;
-            } else {
-                const int root = (int)rp.root_light_samples;
-                const uint32_t per_light = (uint32_t)(root * root);
-                const uint32_t k = q / per_light, r = q % per_light;
-                const int si = (int)(r / (uint32_t)root), sj = (int)(r % (uint32_t)root);
-                const PtcQuadLight& ql = sc.qlights[k];
-                qf.a = P3v(ql.tri1.v1);
-                const vec3 b = P3v(ql.tri1.v2);
-                // `c` is tri2.v3 in direct / pathTracer (:172,712) and tri1.v3 in
-                // computeDirectLight (:380); the loader stores the same point in both.
-                const vec3 c = INTEG == INT_PATHTRACER2 ? P3v(ql.tri1.v3) : P3v(ql.tri2.v3);
-                qf.ab = b - qf.a;
-                qf.ac = c - qf.a;
-                // random numbers of this sample: position in the segment's LCG stream
-                // zeta_0..2 come first (:537-539), a glass hit draws once more (:614)
-                const uint32_t lead = INTEG == INT_PATHTRACER ? (mv.matType == PTC_GLASS ? 4u : 3u) : 0u;
-                uint32_t st = lcg_skip(seed, lead + 2u * q);
-                const float u1 = rnd(st);
-                const float u2 = rnd(st);
-                light_pos = quad_sample(qf, rp.light_stratify != 0u, si, sj, root, u1, u2, INTEG == INT_PATHTRACER2);
-                sh_o = at.P;
-                sh_d = normalize(light_pos - sh_o);
-                sh_tmax = length(light_pos - sh_o) - cf.epsilon;
-                if (INTEG == INT_DIRECT) {
-                    // RayTracer.cu:204-221
-                    const vec3 wdir = normalize(light_pos - sh_o);
-                    const vec3 f_brdf = (P3v(mv.diffuse) / PT_PIf) +
-                                        (P3v(mv.specular) * ((mv.shininess + 2.0f) / (2.0f * PT_PIf)) *
-                                         powf(fmaxf(dot(normalize(reflect(-at.wo, at.normal)), wdir), .0f), mv.shininess));
-                    const vec3 n_light = normalize(cross(qf.ab, qf.ac));
-                    const float R = length(sh_o - light_pos);
-                    const float G = (1.0f / powf(R, 2.0f)) * fmaxf(dot(at.normal, normalize(light_pos - sh_o)), .0f) *
-                                    (fmaxf(dot(n_light, normalize(light_pos - sh_o)), .0f));
-                    term = f_brdf * G;
-                } else if (INTEG == INT_PATHTRACER) {
-                    // RayTracer.cu:745-776
-                    const vec3 n = normalize(at.normal);
-                    const vec3 rr = normalize(reflect(-at.wo, at.normal));
-                    const vec3 w_i_dir = normalize(light_pos - sh_o);
-                    vec3 f_brdf = mk3(.0f);
-                    if (mv.brdf_type == PTC_MOD_PHONG) {
-                        f_brdf = phong_brdf(w_i_dir, rr, mv.shininess, P3v(mv.diffuse), P3v(mv.specular));
-                    } else {
-                        const float wi_dot_n_dir = dot(w_i_dir, n);
-                        const float wo_dot_n_dir = dot(at.wo, n);
-                        if (wi_dot_n_dir > .0f && wo_dot_n_dir > .0f) {
-                            const vec3 f_brdf_GGX = ggx_brdf(w_i_dir, at.wo, n, mv.roughness, P3v(mv.specular));
-                            f_brdf = (P3v(mv.diffuse) / PT_PIf) + f_brdf_GGX;
-                        }
-                    }
-                    const vec3 n_geo = at.normal;  // the inner `n` of :767, not normalised
-                    const vec3 n_light = normalize(cross(qf.ab, qf.ac));
-                    const float R = length(sh_o - light_pos);
-                    const float G = (1.0f / powf(R, 2.0f)) * fmaxf(dot(n_geo, normalize(light_pos - sh_o)), .0f) *
-                                    (fmaxf(dot(n_light, normalize(light_pos - sh_o)), .0f));
-                    term = f_brdf * G;
-                } else if (INTEG == INT_PATHTRACER2) {
-                    // RayTracer.cu:410-420
-                    const float dist = length(light_pos - at.P);
-                    const vec3 n_light = normalize(cross(qf.ab, qf.ac));
-                    const vec3 reflect_dir = reflect(-at.wo, at.normal);
-                    const float G = (1.0f / (dist * dist)) * fmaxf(dot(at.normal, sh_d), .0f) * fmaxf(dot(n_light, sh_d), .0f);
-                    const vec3 f_brdf = phong_brdf(sh_d, reflect_dir, mv.shininess, P3v(mv.diffuse), P3v(mv.specular));
-                    term = f_brdf * G;
-                }
-            }
-            need_ray = !(term.x == 0.f && term.y == 0.f && term.z == 0.f);
+    if (INTEG == INT_RAYTRACER) {
+        // RayTracer.cu:42-86: point lights, then directional lights
+        if (q < sc.n_plights) {
+            const vec3 loc = P3v(sc.plights[q].location);
+            sh_d = normalize(loc - at.P);
+            sh_tmax = length(loc - at.P);
+        } else {
+            sh_d = P3v(sc.dlights[q - sc.n_plights].direction);
+            sh_tmax = PT_RAY_MAX;
         }
-        const size_t plane = (size_t)rp.samples_per_path * ps.capacity;
-        ps.contrib[slot] = term.x;
-        ps.contrib[slot + plane] = term.y;
-        ps.contrib[slot + 2 * plane] = term.z;
+        sh_o = at.P + sh_d * cf.epsilon;
+        const vec3 H = normalize(sh_d + at.wo);
+        vec3 I = P3v(mv.diffuse) * fmaxf(dot(at.normal, sh_d), 0);
+        I += P3v(mv.specular) * powf(fmaxf(dot(at.normal, H), 0), mv.shininess);
+        if (q < sc.n_plights) {
+            const float lightDist = sh_tmax;
+            const float att = dot(P3v(sc.plights[q].attenuation), mk3(1, lightDist, lightDist * lightDist));
+            I *= P3v(sc.plights[q].color) / att;
+        } else {
+            I *= P3v(sc.dlights[q - sc.n_plights].color);
+        }
+        return I;
     }
-    // queue the shadow ray
-    __shared__ uint32_t s_cnt[BLOCK / 64];
-    __shared__ uint32_t s_base;
-    const unsigned long long mask = __ballot(need_ray);
-    const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
-    if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(mask);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t total = 0;
-        for (uint32_t w = 0; w < BLOCK / 64; ++w) total += s_cnt[w];
-        s_base = total ? atomicAdd(shadow_count, total) : 0u;
+    const int root = (int)rp.root_light_samples;
+    const uint32_t per_light = (uint32_t)(root * root);
+    const uint32_t k = q / per_light, r = q % per_light;
+    const int si = (int)(r / (uint32_t)root), sj = (int)(r % (uint32_t)root);
+    const PtcQuadLight& ql = sc.qlights[k];
+    QuadFrame qf;
+    qf.a = P3v(ql.tri1.v1);
+    const vec3 b = P3v(ql.tri1.v2);
+    // `c` is tri2.v3 in direct / pathTracer (:172,712) and tri1.v3 in
+    // computeDirectLight (:380); the loader stores the same point in both.
+    const vec3 c = INTEG == INT_PATHTRACER2 ? P3v(ql.tri1.v3) : P3v(ql.tri2.v3);
+    qf.ab = b - qf.a;
+    qf.ac = c - qf.a;
+    // random numbers of this sample: position in the segment's LCG stream;
+    // zeta_0..2 come first (:537-539), a glass hit draws once more (:614)
+    const uint32_t lead = INTEG == INT_PATHTRACER ? (mv.matType == PTC_GLASS ? 4u : 3u) : 0u;
+    uint32_t st = lcg_skip(seed, lead + 2u * q);
+    const float u1 = rnd(st);
+    const float u2 = rnd(st);
+    const vec3 light_pos = quad_sample(qf, rp.light_stratify != 0u, si, sj, root, u1, u2, INTEG == INT_PATHTRACER2);
+    sh_o = at.P;
+    sh_d = normalize(light_pos - sh_o);
+    sh_tmax = length(light_pos - sh_o) - cf.epsilon;
+    if (INTEG == INT_DIRECT) {
+        // RayTracer.cu:204-221
+        const vec3 wdir = normalize(light_pos - sh_o);
+        const vec3 f_brdf = (P3v(mv.diffuse) / PT_PIf) +
+                            (P3v(mv.specular) * ((mv.shininess + 2.0f) / (2.0f * PT_PIf)) *
+                             powf(fmaxf(dot(normalize(reflect(-at.wo, at.normal)), wdir), .0f), mv.shininess));
+        const vec3 n_light = normalize(cross(qf.ab, qf.ac));
+        const float R = length(sh_o - light_pos);
+        const float G = (1.0f / powf(R, 2.0f)) * fmaxf(dot(at.normal, normalize(light_pos - sh_o)), .0f) *
+                        (fmaxf(dot(n_light, normalize(light_pos - sh_o)), .0f));
+        term = f_brdf * G;
+    } else if (INTEG == INT_PATHTRACER) {
+        // RayTracer.cu:745-776
+        const vec3 n = normalize(at.normal);
+        const vec3 rr = normalize(reflect(-at.wo, at.normal));
+        const vec3 w_i_dir = normalize(light_pos - sh_o);
+        vec3 f_brdf = mk3(.0f);
+        if (mv.brdf_type == PTC_MOD_PHONG) {
+            f_brdf = phong_brdf(w_i_dir, rr, mv.shininess, P3v(mv.diffuse), P3v(mv.specular));
+        } else {
+            const float wi_dot_n_dir = dot(w_i_dir, n);
+            const float wo_dot_n_dir = dot(at.wo, n);
+            if (wi_dot_n_dir > .0f && wo_dot_n_dir > .0f) {
+                const vec3 f_brdf_GGX = ggx_brdf(w_i_dir, at.wo, n, mv.roughness, P3v(mv.specular));
+                f_brdf = (P3v(mv.diffuse) / PT_PIf) + f_brdf_GGX;
+            }
+        }
+        const vec3 n_geo = at.normal;  // the inner `n` of :767, not normalised
+        const vec3 n_light = normalize(cross(qf.ab, qf.ac));
+        const float R = length(sh_o - light_pos);
+        const float G = (1.0f / powf(R, 2.0f)) * fmaxf(dot(n_geo, normalize(light_pos - sh_o)), .0f) *
+                        (fmaxf(dot(n_light, normalize(light_pos - sh_o)), .0f));
+        term = f_brdf * G;
+    } else if (INTEG == INT_PATHTRACER2) {
+        // RayTracer.cu:410-420
+        const float dist = length(light_pos - at.P);
+        const vec3 n_light = normalize(cross(qf.ab, qf.ac));
+        const vec3 reflect_dir = reflect(-at.wo, at.normal);
+        const float G = (1.0f / (dist * dist)) * fmaxf(dot(at.normal, sh_d), .0f) * fmaxf(dot(n_light, sh_d), .0f);
+        const vec3 f_brdf = phong_brdf(sh_d, reflect_dir, mv.shininess, P3v(mv.diffuse), P3v(mv.specular));
+        term = f_brdf * G;
     }
-    __syncthreads();
-    if (need_ray) {
-        uint32_t at_ = s_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-        for (uint32_t w = 0; w < wave; ++w) at_ += s_cnt[w];
-        ps.sh_o[at_] = make_float4(sh_o.x, sh_o.y, sh_o.z, sh_tmax);
-        ps.sh_d[at_] = make_float4(sh_d.x, sh_d.y, sh_d.z, u2f(slot));
-    }
+    return term;
 }
 
 // ------------------------------------------------------------------ shadow --
@@ -733,11 +698,26 @@ __global__ __launch_bounds__(BLOCK) void k_shadow_brute(RenderParams rp, DevScen
     }
 }
 
-// ------------------------------------------------------------------- shade --
+// ----------------------------------------------------------------- surface --
+// What happens at a hit is split in two kernels around the shadow rays:
+//   k_surface  everything that does not need the visibility of the light samples: the
+//              shadow rays + their terms, emission, the sampled direction, the throughput
+//              factor, Russian roulette, the next queue;
+//   k_gather   (after k_shadow) the radiance of the segment, which folds the terms of the
+//              unoccluded light samples in the order the reference's loops add them.
 struct Segment {
     vec3 o, d, thr;
     uint32_t depth, seed;
     bool done;
+};
+
+// gather = false: `a` is the radiance of the segment.
+// gather = true : the segment sampled the lights; `a` is the integrator's constant part
+//                 and k_gather computes the radiance from it, the throughput before this
+//                 segment and the light terms.
+struct SurfaceOut {
+    vec3 a;
+    bool gather;
 };
 
 __device__ __forceinline__ vec3 contrib_at(const RenderParams& rp, const PathState& ps, uint32_t p, uint32_t q) {
@@ -746,13 +726,24 @@ __device__ __forceinline__ vec3 contrib_at(const RenderParams& rp, const PathSta
     return mk3(c[0], c[plane], c[2 * plane]);
 }
 
+// Sum of the light-sample terms of quad light k in loop order.
+__device__ __forceinline__ vec3 light_sum(const RenderParams& rp, const PathState& ps, uint32_t p, uint32_t k, uint32_t per_light) {
+    vec3 s = mk3(.0f);
+    for (uint32_t r = 0; r < per_light; ++r) s += contrib_at(rp, ps, p, k * per_light + r);
+    return s;
+}
+
+__device__ __forceinline__ float quad_area(const PtcQuadLight& ql, bool cdl) {
+    const vec3 a = P3v(ql.tri1.v1), b = P3v(ql.tri1.v2), c = cdl ? P3v(ql.tri1.v3) : P3v(ql.tri2.v3);
+    return length(cross(b - a, c - a));
+}
+
 // RayTracer.cu:34-105
-__device__ __forceinline__ vec3 shade_raytracer(const RenderParams& rp, const DevScene& sc, const PathState& ps, uint32_t p, const HitAttr& at, Segment& sg) {
+__device__ __forceinline__ SurfaceOut surface_raytracer(const RenderParams& rp, const DevScene& sc, const HitAttr& at, Segment& sg) {
     const PtcMaterialValue& mv = material_of(sc, at.mat);
-    vec3 result = P3v(mv.ambient) + P3v(mv.emission);
-    const uint32_t nl = sc.n_plights + sc.n_dlights;
-    for (uint32_t q = 0; q < nl; ++q) result += contrib_at(rp, ps, p, q);  // occluded lights left 0
-    const vec3 radiance = result * sg.thr;
+    const vec3 result = P3v(mv.ambient) + P3v(mv.emission);
+    const bool lights = (sc.n_plights + sc.n_dlights) != 0u;
+    const vec3 a = lights ? result : result * sg.thr;
     if (length(P3v(mv.specular)) > 0) {
         sg.o = at.P;
         sg.d = reflect(-at.wo, at.normal);
@@ -761,11 +752,17 @@ __device__ __forceinline__ vec3 shade_raytracer(const RenderParams& rp, const De
     } else {
         sg.done = true;
     }
-    return radiance;
+    return SurfaceOut{a, lights};
+}
+__device__ __forceinline__ vec3 gather_raytracer(const RenderParams& rp, const DevScene& sc, const PathState& ps, uint32_t p, vec3 a, vec3 thr) {
+    vec3 result = a;
+    const uint32_t nl = sc.n_plights + sc.n_dlights;
+    for (uint32_t q = 0; q < nl; ++q) result += contrib_at(rp, ps, p, q);  // occluded lights left 0
+    return result * thr;
 }
 
 // RayTracer.cu:107-151
-__device__ __forceinline__ vec3 shade_analytic(const RenderParams& rp, const DevScene& sc, const HitAttr& at, Segment& sg) {
+__device__ __forceinline__ SurfaceOut surface_analytic(const RenderParams& rp, const DevScene& sc, const HitAttr& at, Segment& sg) {
     const PtcMaterialValue& mv = material_of(sc, at.mat);
     vec3 result = P3v(mv.ambient) + P3v(mv.emission);
     if (rp.light_samples == 0u) {
@@ -787,30 +784,22 @@ __device__ __forceinline__ vec3 shade_analytic(const RenderParams& rp, const Dev
         }
     }
     sg.done = true;
-    return result;
-}
-
-// Sum of the light-sample terms of quad light k in loop order.
-__device__ __forceinline__ vec3 light_sum(const RenderParams& rp, const PathState& ps, uint32_t p, uint32_t k, uint32_t per_light) {
-    vec3 s = mk3(.0f);
-    for (uint32_t r = 0; r < per_light; ++r) s += contrib_at(rp, ps, p, k * per_light + r);
-    return s;
-}
-
-__device__ __forceinline__ float quad_area(const PtcQuadLight& ql, bool cdl) {
-    const vec3 a = P3v(ql.tri1.v1), b = P3v(ql.tri1.v2), c = cdl ? P3v(ql.tri1.v3) : P3v(ql.tri2.v3);
-    return length(cross(b - a, c - a));
+    return SurfaceOut{result, false};
 }
 
 // RayTracer.cu:153-230
-__device__ __forceinline__ vec3 shade_direct(const RenderParams& rp, const DevScene& sc, const PathState& ps, uint32_t p, const HitAttr& at, Segment& sg) {
+__device__ __forceinline__ SurfaceOut surface_direct(const RenderParams& rp, const DevScene& sc, const HitAttr& at, Segment& sg) {
     const PtcMaterialValue& mv = material_of(sc, at.mat);
-    vec3 result = P3v(mv.ambient) + P3v(mv.emission);
+    const vec3 result = P3v(mv.ambient) + P3v(mv.emission);
     sg.done = true;
     if (is_light(at.mat)) {
         sg.depth = rp.max_depth_eff;
-        return result;
+        return SurfaceOut{result, false};
     }
+    return SurfaceOut{result, sc.n_qlights != 0u};
+}
+__device__ __forceinline__ vec3 gather_direct(const RenderParams& rp, const DevScene& sc, const PathState& ps, uint32_t p, vec3 a) {
+    vec3 result = a;
     const uint32_t per_light = rp.root_light_samples * rp.root_light_samples;
     for (uint32_t k = 0; k < sc.n_qlights; ++k) {
         const float area = fabsf(quad_area(sc.qlights[k], false));
@@ -820,20 +809,15 @@ __device__ __forceinline__ vec3 shade_direct(const RenderParams& rp, const DevSc
 }
 
 // RayTracer.cu:429-494
-__device__ __forceinline__ vec3 shade_pathtracer2(const RenderParams& rp, const DevScene& sc, const PathState& ps, uint32_t p, const HitAttr& at, Segment& sg) {
+__device__ __forceinline__ SurfaceOut surface_pathtracer2(const RenderParams& rp, const DevScene& sc, const HitAttr& at, Segment& sg) {
     const PtcMaterialValue& mv = material_of(sc, at.mat);
     const vec3 L_e = P3v(mv.emission);
     if (sg.depth > 0u && is_light(at.mat)) {
         sg.depth = rp.max_depth_eff;
         sg.done = true;
-        return mk3(.0f);
+        return SurfaceOut{mk3(.0f), false};
     }
     const uint32_t per_light = rp.root_light_samples * rp.root_light_samples;
-    vec3 L_d = mk3(.0f);
-    for (uint32_t k = 0; k < sc.n_qlights; ++k) {
-        const float area = fabsf(quad_area(sc.qlights[k], true));
-        L_d += P3v(sc.qlights[k].color) * (area / (float)rp.light_samples) * light_sum(rp, ps, p, k, per_light);
-    }
     uint32_t st = lcg_skip(sg.seed, 2u * per_light * sc.n_qlights);
     const float zeta1 = rnd(st), zeta2 = rnd(st);
     const PolarAngle theta = angle_acos(zeta1);
@@ -851,18 +835,29 @@ __device__ __forceinline__ vec3 shade_pathtracer2(const RenderParams& rp, const 
     const vec3 attenuation = (f_brdf * fmaxf(dot(norm, w_i), .0f)) * (1.0f / pdf);
     vec3 radiance = mk3(.0f);
     if (sg.depth == 0u) radiance += L_e * sg.thr;
-    radiance += L_d * sg.thr;
+    // "radiance += L_d * throughput" (:471) happens in gather_pathtracer2
     sg.thr *= attenuation;
     const float q = fminf(fmaxf(fmaxf(sg.thr.x, sg.thr.y), sg.thr.z), 1.0f);
     if (rnd(st) > q) {
         sg.depth = rp.max_depth_eff;
         sg.done = true;
-        return radiance;
+        return SurfaceOut{radiance, true};
     }
     sg.thr *= 1.0f / (q);
     sg.o = at.P;
     sg.d = w_i;
     sg.depth++;
+    return SurfaceOut{radiance, true};
+}
+__device__ __forceinline__ vec3 gather_pathtracer2(const RenderParams& rp, const DevScene& sc, const PathState& ps, uint32_t p, vec3 a, vec3 thr) {
+    const uint32_t per_light = rp.root_light_samples * rp.root_light_samples;
+    vec3 L_d = mk3(.0f);
+    for (uint32_t k = 0; k < sc.n_qlights; ++k) {
+        const float area = fabsf(quad_area(sc.qlights[k], true));
+        L_d += P3v(sc.qlights[k].color) * (area / (float)rp.light_samples) * light_sum(rp, ps, p, k, per_light);
+    }
+    vec3 radiance = a;
+    radiance += L_d * thr;
     return radiance;
 }
 
@@ -882,18 +877,15 @@ __device__ __forceinline__ float sample_phase_hg(float g, float zeta) {
     return phase_hg(-cos_theta, g);
 }
 
-// RayTracer.cu:496-963, all three material types.
-__device__ __forceinline__ vec3 shade_pathtracer(const RenderParams& rp, const DevScene& sc, const PathState& ps, uint32_t p, const HitAttr& at, Segment& sg) {
+// RayTracer.cu:496-963, all three material types, without the light sum (gather_pathtracer).
+__device__ __forceinline__ SurfaceOut surface_pathtracer(const RenderParams& rp, const DevScene& sc, const HitAttr& at, Segment& sg) {
     const PtcMaterialValue& mv = material_of(sc, at.mat);
     const PtcConfig& cf = rp.cf;
-    vec3 result = mk3(.0f);
-    vec3 L_d = mk3(.0f);
     const vec3 n = normalize(at.normal);
     const vec3 L_e = P3v(mv.emission), K_s = P3v(mv.specular), K_d = P3v(mv.diffuse);
     const vec3 r = normalize(reflect(-at.wo, at.normal));
     PolarAngle theta = angle_zero();
     float phi = .0f;
-    const float exp_beta = 2.0f;
     vec3 w_i = mk3(.0f);
     vec3 addon_throughput = mk3(1.0f);
     vec3 new_pos = mk3(.0f);  // :517
@@ -901,7 +893,7 @@ __device__ __forceinline__ vec3 shade_pathtracer(const RenderParams& rp, const D
     if (cf.next_event_est && is_light(at.mat) && sg.depth != 0u) {  // :528-533
         sg.depth = rp.max_depth_eff;
         sg.done = true;
-        return result;
+        return SurfaceOut{mk3(.0f), false};
     }
     uint32_t st = sg.seed;
     const float zeta_0 = rnd(st), zeta_1 = rnd(st), zeta_2 = rnd(st);
@@ -966,27 +958,7 @@ __device__ __forceinline__ vec3 shade_pathtracer(const RenderParams& rp, const D
         w_i = normalize(reflect(-at.wo, spherical_dir(theta_h_sample, phi_h_sample, u_h, v_h, n)));
     }
 
-    if (cf.next_event_est) {  // :700-801
-        const uint32_t per_light = rp.root_light_samples * rp.root_light_samples;
-        for (uint32_t k = 0; k < sc.n_qlights; ++k) {
-            const vec3 sampled_result = light_sum(rp, ps, p, k, per_light);
-            const float area = quad_area(sc.qlights[k], false);
-            if (cf.next_event_est == PTC_NEE_MIS) {
-                // :782-794 as written: pdf_lights_k, D and h are never assigned, so
-                // pdf_NEE = 0 and pdf_brdf carries a 0/0 term.
-                const float pdf_NEE = .0f, D = .0f;
-                const vec3 h = mk3(.0f), w_i_dir = mk3(.0f);
-                const float pdf_brdf = ((1.0f - t) * fmaxf(dot(n, w_i_dir), .0f) / PT_PIf) + ((t * D * dot(n, h)) / (4.0f * dot(h, w_i_dir)));
-                const float pdf_denom_sum = powf(pdf_NEE, exp_beta) + powf(pdf_brdf, exp_beta);
-                const float pdf_numerator = powf(pdf_NEE, exp_beta);
-                const float weight_i = pdf_numerator / pdf_denom_sum;
-                L_d += P3v(sc.qlights[k].color) * sampled_result * (area / (float)rp.light_samples) * (1.0f / pdf_NEE) * weight_i;
-            } else {
-                L_d += P3v(sc.qlights[k].color) * sampled_result * (area / (float)rp.light_samples);  // :798
-            }
-        }
-        st = lcg_skip(st, 2u * per_light * sc.n_qlights);  // the u1,u2 of every light sample
-    }
+    if (cf.next_event_est) st = lcg_skip(st, 2u * rp.root_light_samples * rp.root_light_samples * sc.n_qlights);  // the u1,u2 of every light sample (:724-725)
 
     vec3 f_brdf = mk3(1.0f);
     float pdf = 1.0f;
@@ -1024,10 +996,12 @@ __device__ __forceinline__ vec3 shade_pathtracer(const RenderParams& rp, const D
             break;
     }
 
-    if (cf.next_event_est && (sg.depth == 0u)) result += L_e + L_d;  // :900-917
-    else if (cf.next_event_est == PTC_NEE_ON || cf.next_event_est == PTC_NEE_MIS) result += L_d;
-    else result += L_e;
-    const vec3 radiance = result * sg.thr;  // :918
+    // :900-917: result = L_e + L_d at the first hit with NEE, L_d alone later, L_e without
+    // NEE; L_d is added by gather_pathtracer
+    SurfaceOut out;
+    out.gather = cf.next_event_est != 0u;
+    const bool with_Le = !cf.next_event_est || sg.depth == 0u;
+    out.a = out.gather ? (with_Le ? L_e : mk3(.0f)) : L_e * sg.thr;
 
     if (cf.russian_roul) {  // :923-933, q from the throughput BEFORE this bounce's factor
         const float q = 1.0f - fminf(fmaxf(fmaxf(sg.thr.x, sg.thr.y), sg.thr.z), 1.0f);
@@ -1039,42 +1013,122 @@ __device__ __forceinline__ vec3 shade_pathtracer(const RenderParams& rp, const D
     sg.o = (mv.matType == PTC_GLASS || mv.matType == PTC_VOLUMETRIC) ? new_pos : at.P;
     sg.d = w_i;
     sg.depth++;  // :959-962 (the condition there is a tautology)
-    return radiance;
+    return out;
+}
+
+__device__ __forceinline__ vec3 gather_pathtracer(const RenderParams& rp, const DevScene& sc, const PathState& ps, uint32_t p, vec3 a, vec3 thr, bool with_Le) {
+    const PtcConfig& cf = rp.cf;
+    const uint32_t per_light = rp.root_light_samples * rp.root_light_samples;
+    vec3 L_d = mk3(.0f);
+    for (uint32_t k = 0; k < sc.n_qlights; ++k) {  // :702-800
+        const vec3 sampled_result = light_sum(rp, ps, p, k, per_light);
+        const float area = quad_area(sc.qlights[k], false);
+        if (cf.next_event_est == PTC_NEE_MIS) {
+            // :782-794 as written: pdf_lights_k, D and h are never assigned, so
+            // pdf_NEE = 0 and pdf_brdf carries a 0/0 term.
+            const float exp_beta = 2.0f, pdf_NEE = .0f, pdf_brdf = __builtin_nanf("");
+            const float pdf_denom_sum = powf(pdf_NEE, exp_beta) + powf(pdf_brdf, exp_beta);
+            const float pdf_numerator = powf(pdf_NEE, exp_beta);
+            const float weight_i = pdf_numerator / pdf_denom_sum;
+            L_d += P3v(sc.qlights[k].color) * sampled_result * (area / (float)rp.light_samples) * (1.0f / pdf_NEE) * weight_i;
+        } else {
+            L_d += P3v(sc.qlights[k].color) * sampled_result * (area / (float)rp.light_samples);  // :798
+        }
+    }
+    vec3 result = mk3(.0f);
+    if (with_Le) result += a + L_d;  // :902
+    else result += L_d;              // :908
+    return result * thr;             // :918
 }
 
 template <int INTEG>
-__global__ __launch_bounds__(GEN_BLOCK) void k_shade(RenderParams rp, DevScene sc, PathState ps, const uint32_t* __restrict__ queue,
-                                                     const uint32_t* __restrict__ count_ptr, uint32_t npix_pad, uint32_t sample_begin,
-                                                     uint32_t* __restrict__ segctr, uint32_t* __restrict__ next_queue, uint32_t* __restrict__ next_count) {
-    const uint32_t count = *count_ptr;  // hits of this bounce, written by k_extend
+__device__ __forceinline__ vec3 gather_radiance(const RenderParams& rp, const DevScene& sc, const PathState& ps, uint32_t p, vec3 a, vec3 thr, bool with_Le) {
+    if (INTEG == INT_RAYTRACER) return gather_raytracer(rp, sc, ps, p, a, thr);
+    if (INTEG == INT_DIRECT) return gather_direct(rp, sc, ps, p, a);
+    if (INTEG == INT_PATHTRACER2) return gather_pathtracer2(rp, sc, ps, p, a, thr);
+    if (INTEG == INT_PATHTRACER) return gather_pathtracer(rp, sc, ps, p, a, thr, with_Le);
+    return a;
+}
+
+// One thread per path of the bounce that hit something.
+template <int INTEG>
+__global__ __launch_bounds__(GEN_BLOCK) void k_surface(RenderParams rp, DevScene sc, PathState ps, const uint32_t* __restrict__ queue,
+                                                       const uint32_t* __restrict__ count_ptr, uint32_t npix_pad, uint32_t sample_begin, uint32_t* __restrict__ segctr,
+                                                       uint32_t* __restrict__ next_queue, uint32_t* __restrict__ next_count,
+                                                       uint32_t* __restrict__ gather_queue, uint32_t* __restrict__ gather_count,
+                                                       uint32_t* __restrict__ shadow_count) {
+    const uint32_t count = *count_ptr;  // hits of this bounce, written by k_compact_hits
+    if (blockIdx.x * GEN_BLOCK >= count) return;
     const uint32_t i = blockIdx.x * GEN_BLOCK + threadIdx.x;
-    bool alive = false;
-    uint32_t p = 0;
-    if (i < count) {
+    const bool hit = i < count;
+    bool sample = false, alive = false, gather = false;
+    uint32_t p = 0, bounce = 0;
+    Segment sg;
+    HitAttr at;
+    if (hit) {
         p = queue[i];
         const float4 o4 = ps.o_seed[p], d4 = ps.d_depth[p], t4 = ps.thr[p];
-        Segment sg;
         sg.o = mk3(o4.x, o4.y, o4.z);
         sg.d = mk3(d4.x, d4.y, d4.z);
         sg.thr = mk3(t4.x, t4.y, t4.z);
         sg.seed = f2u(o4.w);
         sg.depth = f2u(d4.w);
         sg.done = false;
-        uint32_t bounce = f2u(t4.w);
-        const int ref = ps.hit_ref[p];
-        vec3 radiance;
-        HitAttr at;  // only paths with a hit are queued here
-        hit_attributes(sc, ref, ps.hit_t[p], sg.o, sg.d, at);
-        if (INTEG == INT_RAYTRACER) radiance = shade_raytracer(rp, sc, ps, p, at, sg);
-        else if (INTEG == INT_ANALYTICDIRECT) radiance = shade_analytic(rp, sc, at, sg);
-        else if (INTEG == INT_DIRECT) radiance = shade_direct(rp, sc, ps, p, at, sg);
-        else if (INTEG == INT_PATHTRACER2) radiance = shade_pathtracer2(rp, sc, ps, p, at, sg);
-        else radiance = shade_pathtracer(rp, sc, ps, p, at, sg);
-        float4 L = ps.L[p];
-        L.x += radiance.x;  // PinholeCamera.cu:61
-        L.y += radiance.y;
-        L.z += radiance.z;
-        ps.L[p] = L;
+        bounce = f2u(t4.w);
+        hit_attributes(sc, ps.hit_ref[p], ps.hit_t[p], sg.o, sg.d, at);
+        sample = rp.samples_per_path != 0u && samples_lights<INTEG>(rp, at.mat, sg.depth);
+    }
+    // ---- the light samples: term + shadow ray each; a term that is exactly zero adds
+    // nothing whether or not the ray is blocked, so no ray is queued for it; any other value
+    // (NaN included) is stored and its ray queued; k_shadow zeroes the term of an occluded ray
+    if (INTEG != INT_ANALYTICDIRECT) {
+        const size_t plane = (size_t)rp.samples_per_path * ps.capacity;
+        for (uint32_t q = 0; q < rp.samples_per_path; ++q) {
+            vec3 sh_o = mk3(0.f), sh_d = mk3(0.f);
+            float sh_tmax = 0.f;
+            bool need_ray = false;
+            uint32_t slot = 0;
+            if (sample) {
+                const vec3 term = light_sample<INTEG>(rp, sc, at, material_of(sc, at.mat), sg.seed, q, sh_o, sh_d, sh_tmax);
+                need_ray = !(term.x == 0.f && term.y == 0.f && term.z == 0.f);
+                slot = contrib_slot(ps, p, q);
+                ps.contrib[slot] = term.x;
+                ps.contrib[slot + plane] = term.y;
+                ps.contrib[slot + 2 * plane] = term.z;
+            }
+            const uint32_t at_ = queue_reserve(need_ray, shadow_count);
+            if (need_ray) {
+                ps.sh_o[at_] = make_float4(sh_o.x, sh_o.y, sh_o.z, sh_tmax);
+                ps.sh_d[at_] = make_float4(sh_d.x, sh_d.y, sh_d.z, u2f(slot));
+            }
+        }
+    }
+    // ---- the rest of the closest-hit program
+    if (hit) {
+        const vec3 thr_before = sg.thr;
+        const uint32_t depth_before = sg.depth;
+        SurfaceOut out;
+        if (INTEG == INT_RAYTRACER) out = surface_raytracer(rp, sc, at, sg);
+        else if (INTEG == INT_ANALYTICDIRECT) out = surface_analytic(rp, sc, at, sg);
+        else if (INTEG == INT_DIRECT) out = surface_direct(rp, sc, at, sg);
+        else if (INTEG == INT_PATHTRACER2) out = surface_pathtracer2(rp, sc, at, sg);
+        else out = surface_pathtracer(rp, sc, at, sg);
+        gather = out.gather && sample;
+        if (gather) {
+            // w: does the first-hit rule of pathTracer include the emission (:900-903)
+            ps.g_a[p] = make_float4(out.a.x, out.a.y, out.a.z, u2f((!rp.cf.next_event_est || depth_before == 0u) ? 1u : 0u));
+            ps.g_thr[p] = make_float4(thr_before.x, thr_before.y, thr_before.z, 0.f);
+        } else {
+            // gather wanted but there is not a single light sample (lightsamples 0): the same
+            // formulas over zero terms, here
+            vec3 radiance = out.a;
+            if (out.gather) radiance = gather_radiance<INTEG>(rp, sc, ps, p, out.a, thr_before, !rp.cf.next_event_est || depth_before == 0u);
+            float4 L = ps.L[p];
+            L.x += radiance.x;  // PinholeCamera.cu:61
+            L.y += radiance.y;
+            L.z += radiance.z;
+            ps.L[p] = L;
+        }
         ++bounce;
         // PinholeCamera.cu:66 plus the segment cap and the zero-throughput cull
         alive = !sg.done && sg.depth != rp.max_depth_eff && bounce < rp.bounce_cap;
@@ -1090,7 +1144,25 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_shade(RenderParams rp, DevScene s
             ps.thr[p] = make_float4(sg.thr.x, sg.thr.y, sg.thr.z, u2f(bounce));
         }
     }
+    queue_append(gather, p, gather_queue, gather_count);
     queue_append(alive, p, next_queue, next_count);
+}
+
+// After k_shadow: the radiance of the segments that sampled the lights.
+template <int INTEG>
+__global__ __launch_bounds__(GEN_BLOCK) void k_gather(RenderParams rp, DevScene sc, PathState ps, const uint32_t* __restrict__ gather_queue,
+                                                      const uint32_t* __restrict__ gather_count) {
+    const uint32_t i = blockIdx.x * GEN_BLOCK + threadIdx.x;
+    if (i >= *gather_count) return;
+    const uint32_t p = gather_queue[i];
+    const float4 a4 = ps.g_a[p], t4 = ps.g_thr[p];
+    const vec3 a = mk3(a4.x, a4.y, a4.z), thr = mk3(t4.x, t4.y, t4.z);
+    const vec3 radiance = gather_radiance<INTEG>(rp, sc, ps, p, a, thr, f2u(a4.w) != 0u);
+    float4 L = ps.L[p];
+    L.x += radiance.x;  // PinholeCamera.cu:61
+    L.y += radiance.y;
+    L.z += radiance.z;
+    ps.L[p] = L;
 }
 
 // -------------------------------------------------------------- accumulate --
@@ -1224,27 +1296,7 @@ void wf_extend(hipStream_t s, const RenderParams& rp, const DevScene& sc, const 
         hipLaunchKernelGGL(k_extend<false>, dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, queue, count, work_counter, wave_chunk, trav_counters);
 }
 
-// Queue of the paths whose extension ray hit something; misses end there.
-void wf_compact_hits(hipStream_t s, const RenderParams& rp, const PathState& ps, const uint32_t* queue, uint32_t count, uint32_t* hit_queue, uint32_t* hit_count) {
-    if (count == 0) return;
-    hipLaunchKernelGGL(k_compact_hits, dim3(blocks_for(count, GEN_BLOCK)), dim3(GEN_BLOCK), 0, s, rp, ps, queue, count, hit_queue, hit_count);
-}
-
-// `count_ptr` (device) holds the number of queued paths; `max_count` bounds it and sizes the grid.
-void wf_connect(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, const uint32_t* count_ptr,
-                uint32_t max_count, uint32_t n_samples, uint32_t* shadow_count) {
-    if (max_count == 0 || n_samples == 0) return;
-    const dim3 g(blocks_for((uint64_t)max_count * n_samples)), b(BLOCK);
-    switch (rp.integrator) {
-        case INT_RAYTRACER: hipLaunchKernelGGL(k_connect<INT_RAYTRACER>, g, b, 0, s, rp, sc, ps, queue, count_ptr, n_samples, shadow_count); break;
-        case INT_DIRECT: hipLaunchKernelGGL(k_connect<INT_DIRECT>, g, b, 0, s, rp, sc, ps, queue, count_ptr, n_samples, shadow_count); break;
-        case INT_PATHTRACER: hipLaunchKernelGGL(k_connect<INT_PATHTRACER>, g, b, 0, s, rp, sc, ps, queue, count_ptr, n_samples, shadow_count); break;
-        case INT_PATHTRACER2: hipLaunchKernelGGL(k_connect<INT_PATHTRACER2>, g, b, 0, s, rp, sc, ps, queue, count_ptr, n_samples, shadow_count); break;
-        default: break;
-    }
-}
-
-// Traces the shadow rays k_connect queued (their number is in device memory, at most `max_rays`).
+// Traces the shadow rays k_surface queued (their number is in device memory, at most `max_rays`).
 void wf_shadow(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* count_ptr, uint64_t max_rays,
                uint32_t* work_counter, uint32_t resident_waves, bool count_trav, unsigned long long* trav_counters, unsigned long long* shadow_total) {
     if (max_rays == 0) return;
@@ -1276,16 +1328,40 @@ uint32_t wf_resident_waves(int device) {
     return (uint32_t)per_cu * (uint32_t)cus * (BLOCK / 64);
 }
 
-void wf_shade(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, const uint32_t* count_ptr,
-              uint32_t max_count, uint32_t npix_pad, uint32_t sample_begin, uint32_t* segctr, uint32_t* next_queue, uint32_t* next_count) {
+// Queue of the paths whose extension ray hit something; misses end there.
+void wf_compact_hits(hipStream_t s, const RenderParams& rp, const PathState& ps, const uint32_t* queue, uint32_t count, uint32_t* hit_queue, uint32_t* hit_count) {
+    if (count == 0) return;
+    hipLaunchKernelGGL(k_compact_hits, dim3(blocks_for(count, GEN_BLOCK)), dim3(GEN_BLOCK), 0, s, rp, ps, queue, count, hit_queue, hit_count);
+}
+
+// `count_ptr` (device) holds the number of queued paths; `max_count` bounds it and sizes the grid.
+void wf_surface(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, const uint32_t* count_ptr,
+                uint32_t max_count, uint32_t npix_pad, uint32_t sample_begin, uint32_t* segctr, uint32_t* next_queue, uint32_t* next_count,
+                uint32_t* gather_queue, uint32_t* gather_count, uint32_t* shadow_count) {
+    if (max_count == 0) return;
+    const dim3 g(blocks_for(max_count, GEN_BLOCK)), b(GEN_BLOCK);
+#define PT_SURFACE(I) hipLaunchKernelGGL(k_surface<I>, g, b, 0, s, rp, sc, ps, queue, count_ptr, npix_pad, sample_begin, segctr, next_queue, next_count, gather_queue, gather_count, shadow_count)
+    switch (rp.integrator) {
+        case INT_RAYTRACER: PT_SURFACE(INT_RAYTRACER); break;
+        case INT_ANALYTICDIRECT: PT_SURFACE(INT_ANALYTICDIRECT); break;
+        case INT_DIRECT: PT_SURFACE(INT_DIRECT); break;
+        case INT_PATHTRACER: PT_SURFACE(INT_PATHTRACER); break;
+        case INT_PATHTRACER2: PT_SURFACE(INT_PATHTRACER2); break;
+        default: break;
+    }
+#undef PT_SURFACE
+}
+
+// `gather_count` (device) holds the number of queued paths; `max_count` bounds it and sizes the grid.
+void wf_gather(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* gather_queue, const uint32_t* gather_count,
+               uint32_t max_count) {
     if (max_count == 0) return;
     const dim3 g(blocks_for(max_count, GEN_BLOCK)), b(GEN_BLOCK);
     switch (rp.integrator) {
-        case INT_RAYTRACER: hipLaunchKernelGGL(k_shade<INT_RAYTRACER>, g, b, 0, s, rp, sc, ps, queue, count_ptr, npix_pad, sample_begin, segctr, next_queue, next_count); break;
-        case INT_ANALYTICDIRECT: hipLaunchKernelGGL(k_shade<INT_ANALYTICDIRECT>, g, b, 0, s, rp, sc, ps, queue, count_ptr, npix_pad, sample_begin, segctr, next_queue, next_count); break;
-        case INT_DIRECT: hipLaunchKernelGGL(k_shade<INT_DIRECT>, g, b, 0, s, rp, sc, ps, queue, count_ptr, npix_pad, sample_begin, segctr, next_queue, next_count); break;
-        case INT_PATHTRACER: hipLaunchKernelGGL(k_shade<INT_PATHTRACER>, g, b, 0, s, rp, sc, ps, queue, count_ptr, npix_pad, sample_begin, segctr, next_queue, next_count); break;
-        case INT_PATHTRACER2: hipLaunchKernelGGL(k_shade<INT_PATHTRACER2>, g, b, 0, s, rp, sc, ps, queue, count_ptr, npix_pad, sample_begin, segctr, next_queue, next_count); break;
+        case INT_RAYTRACER: hipLaunchKernelGGL(k_gather<INT_RAYTRACER>, g, b, 0, s, rp, sc, ps, gather_queue, gather_count); break;
+        case INT_DIRECT: hipLaunchKernelGGL(k_gather<INT_DIRECT>, g, b, 0, s, rp, sc, ps, gather_queue, gather_count); break;
+        case INT_PATHTRACER: hipLaunchKernelGGL(k_gather<INT_PATHTRACER>, g, b, 0, s, rp, sc, ps, gather_queue, gather_count); break;
+        case INT_PATHTRACER2: hipLaunchKernelGGL(k_gather<INT_PATHTRACER2>, g, b, 0, s, rp, sc, ps, gather_queue, gather_count); break;
         default: break;
     }
 }

@@ -7,6 +7,7 @@ timeout -k 10 600 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout
 tail -2 gpurun_out/${tag}_gpu_tests.log
 timeout -k 10 300 python bench.py 2>/dev/null > gpurun_out/${tag}_bench.json
 cat gpurun_out/${tag}_bench.json
+rm -rf gpurun_out/${tag}_prof
 export TMPDIR=/tmp
 root=$PWD
 cd /tmp
