@@ -467,7 +467,10 @@ void emitTree(const std::vector<int>& left, const std::vector<int>& right, const
 // PLOC over the n Morton-sorted primitives; returns the tree on the host.
 std::string plocBuild(hipStream_t s, const Box6* d_boxes, const uint32_t* d_sorted, int n, float pad, std::vector<int>& left, std::vector<int>& right,
                       std::vector<Box6>& box, int& root) {
-    const int radius = 10;
+#ifndef PLOC_RADIUS
+#define PLOC_RADIUS 50
+#endif
+    const int radius = PLOC_RADIUS;
     DevBuf<Box6> node_box;
     DevBuf<int> cl_a, cl_b, cl_out, nn, valid, pos, d_left, d_right, node_count;
     HIPCHK(node_box.alloc(2 * (size_t)n)); HIPCHK(cl_a.alloc(n)); HIPCHK(cl_b.alloc(n)); HIPCHK(cl_out.alloc(n));

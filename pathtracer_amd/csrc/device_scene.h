@@ -43,7 +43,9 @@ static_assert(sizeof(BvhNode) == 64, "BVH node is 64 bytes");
 #define REF_FIRST(r) ((r)&0x07FFFFFFu)
 #define REF_COUNT(r) ((((r) >> 27) & 7u) + 1u)
 #define MAKE_LEAF(kind, first, count) (((uint32_t)(kind) << 30) | ((uint32_t)((count)-1u) << 27) | (uint32_t)(first))
+#ifndef BVH_LEAF_MAX
 #define BVH_LEAF_MAX 4  /* primitives per collapsed LBVH leaf */
+#endif
 #define BVH_BIG_MAX 8   /* primitives per top-level "large primitive" leaf */
 
 // Traversal stack: entries per thread kept in LDS, further entries in per-thread
@@ -93,6 +95,7 @@ struct RenderParams {
     int32_t integrator;
     float bg[3];
     uint32_t width, height;
+    double inv_tiles_x, inv_npix_pad;  // reciprocals of the 8x8-tile columns and of the padded pixel count
     uint32_t frame_id;
     uint32_t max_depth_eff;   // min(cf.maxDepth, bounce cap)
     uint32_t bounce_cap;

@@ -264,6 +264,11 @@ int makeParams(ptc_context* ctx, int frame_id, uint32_t w, uint32_t h, RenderPar
     if (!ctx->built) return fail(ctx, PTC_ERR_NOT_BUILT, "ptc_build has not been called since the last geometry upload");
     std::memset(&rp, 0, sizeof(rp));
     rp.cf = ctx->cfg;
+    {
+        const uint32_t tiles_x = (w + 7u) / 8u, tiles_y = (h + 7u) / 8u;
+        rp.inv_tiles_x = 1.0 / (double)std::max(tiles_x, 1u);
+        rp.inv_npix_pad = 1.0 / (double)std::max(tiles_x * tiles_y * 64u, 1u);
+    }
     rp.cf.next_event_est = ctx->next_event_est;
     rp.light_samples = ctx->light_samples;
     rp.light_stratify = ctx->light_stratify;

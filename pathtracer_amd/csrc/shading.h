@@ -81,10 +81,11 @@ __device__ __forceinline__ PolarAngle angle_atan(float a, bool libm_chain) {
     return PolarAngle{c, a * c};
 }
 
-// RayTracer.cu:316-322
-__device__ __forceinline__ vec3 spherical_dir(PolarAngle theta, float phi, vec3 u, vec3 v, vec3 w) {
+// RayTracer.cu:316-322.  The azimuth is always 2*pi*zeta in the source; it is passed here
+// as zeta ("turns") so that sine and cosine need no reduction by an inexact 2*pi.
+__device__ __forceinline__ vec3 spherical_dir(PolarAngle theta, float phi_turns, vec3 u, vec3 v, vec3 w) {
     float sp, cp;
-    sincosf(phi, &sp, &cp);
+    sincospif(2.0f * phi_turns, &sp, &cp);
     vec3 s = mk3(cp * theta.s, sp * theta.s, theta.c);
     return normalize((s.x * u + s.y * v + s.z * w));
 }
@@ -101,19 +102,19 @@ __device__ __forceinline__ void gen_coord_frame(int semantics, vec3 w, vec3& u, 
 }
 
 // RayTracer.cu:232-257 (by-value outputs under literal semantics).
-__device__ __forceinline__ void compute_polar_angles(int semantics, uint32_t sampling_method, float& phi, PolarAngle& theta, float z0, float z1, float z2, float t, float shininess) {
+__device__ __forceinline__ void compute_polar_angles(int semantics, uint32_t sampling_method, float& phi_turns, PolarAngle& theta, float z0, float z1, float z2, float t, float shininess) {
     if (semantics != 1) return;
     switch (sampling_method) {
         case PTC_HEMISPHERE_SAMPLING:
-            phi = 2.0f * PT_PIf * z2;
+            phi_turns = z2;
             theta = angle_acos(z1);
             break;
         case PTC_COSINE_SAMPLING:
-            phi = 2.0f * PT_PIf * z2;
+            phi_turns = z2;
             theta = angle_acos(sqrtf(z1));
             break;
         case PTC_BRDF_SAMPLING:
-            phi = 2.0f * PT_PIf * z2;
+            phi_turns = z2;
             if (z0 > t)
                 theta = angle_acos(sqrtf(z1));
             else

@@ -49,11 +49,30 @@ __device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
 
 // Map a padded pixel number to image coordinates: 64 consecutive numbers form
 // an 8x8 tile, so one wave traces a compact bundle of camera rays.
+// n / d and n % d for a divisor that is the same for the whole launch: one fp64 multiply
+// by the host-computed reciprocal (the product is within one of the quotient for any
+// 32-bit n) and a fix-up, instead of the ~40-instruction integer division sequence.
+__device__ __forceinline__ uint32_t div_by(uint32_t n, uint32_t d, double inv_d, uint32_t& rem) {
+    uint32_t q = (uint32_t)((double)n * inv_d);
+    int64_t r = (int64_t)n - (int64_t)q * d;
+    if (r < 0) {
+        --q;
+        r += d;
+    } else if (r >= (int64_t)d) {
+        ++q;
+        r -= d;
+    }
+    rem = (uint32_t)r;
+    return q;
+}
+
 __device__ __forceinline__ bool pixel_of(const RenderParams& rp, uint32_t pix, uint32_t& x, uint32_t& y) {
     const uint32_t tiles_x = (rp.width + 7u) >> 3;
     const uint32_t tile = pix >> 6, in = pix & 63u;
-    x = (tile % tiles_x) * 8u + (in & 7u);
-    y = (tile / tiles_x) * 8u + (in >> 3);
+    uint32_t tx;
+    const uint32_t ty = div_by(tile, tiles_x, rp.inv_tiles_x, tx);
+    x = tx * 8u + (in & 7u);
+    y = ty * 8u + (in >> 3);
     return x < rp.width && y < rp.height;
 }
 
@@ -89,6 +108,51 @@ __device__ __forceinline__ void queue_append(bool keep, uint32_t value, uint32_t
     if (keep) out[at] = value;
 }
 
+// The same for four streams at once, with one round of barriers: streams 0 and 1 go to
+// `c01` (all of stream 0 of the block, then all of stream 1), stream 2 to `c2`, stream 3
+// to `c3`.  at[k] receives the position for the streams this thread appends to.
+__device__ __forceinline__ void queue_reserve4(bool k0, bool k1, bool k2, bool k3, uint32_t* __restrict__ c01, uint32_t* __restrict__ c2, uint32_t* __restrict__ c3,
+                                               uint32_t at[4]) {
+    __shared__ uint32_t s_cnt[16][4];
+    __shared__ uint32_t s_base[4];
+    const uint32_t lane = __lane_id();
+    const uint32_t wave = threadIdx.x >> 6, nwaves = (blockDim.x + 63u) >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1), m2 = __ballot(k2), m3 = __ballot(k3);
+    __syncthreads();  // the previous call's readers are done
+    if (lane == 0) {
+        s_cnt[wave][0] = (uint32_t)__popcll(m0);
+        s_cnt[wave][1] = (uint32_t)__popcll(m1);
+        s_cnt[wave][2] = (uint32_t)__popcll(m2);
+        s_cnt[wave][3] = (uint32_t)__popcll(m3);
+    }
+    __syncthreads();
+    if (threadIdx.x < 3u) {
+        uint32_t t0 = 0, t1 = 0;
+        const uint32_t k = threadIdx.x == 0u ? 0u : threadIdx.x + 1u;
+        for (uint32_t w = 0; w < nwaves; ++w) {
+            t0 += s_cnt[w][k];
+            if (threadIdx.x == 0u) t1 += s_cnt[w][1];
+        }
+        uint32_t* c = threadIdx.x == 0u ? c01 : threadIdx.x == 1u ? c2 : c3;
+        const uint32_t b = (t0 + t1) ? atomicAdd(c, t0 + t1) : 0u;
+        s_base[k] = b;
+        if (threadIdx.x == 0u) s_base[1] = b + t0;
+    }
+    __syncthreads();
+    uint32_t b0 = s_base[0], b1 = s_base[1], b2 = s_base[2], b3 = s_base[3];
+    for (uint32_t w = 0; w < wave; ++w) {
+        b0 += s_cnt[w][0];
+        b1 += s_cnt[w][1];
+        b2 += s_cnt[w][2];
+        b3 += s_cnt[w][3];
+    }
+    at[0] = b0 + (uint32_t)__popcll(m0 & lt);
+    at[1] = b1 + (uint32_t)__popcll(m1 & lt);
+    at[2] = b2 + (uint32_t)__popcll(m2 & lt);
+    at[3] = b3 + (uint32_t)__popcll(m3 & lt);
+}
+
 __device__ __forceinline__ uint32_t segment_seed(const RenderParams& rp, uint32_t key0, uint32_t sample, uint32_t bounce, uint32_t* segctr, uint32_t pix) {
     if (rp.seeding == 0) {  // PinholeCamera.cu:56, i++ over the pixel's whole history
         uint32_t i = segctr[pix];
@@ -106,8 +170,7 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_generate(RenderParams rp, PathSta
     bool valid = p < n_paths;
     uint32_t x = 0, y = 0, pix = 0, j = 0;
     if (valid) {
-        pix = p % npix_pad;
-        j = sample_begin + p / npix_pad;
+        j = sample_begin + div_by(p, npix_pad, rp.inv_npix_pad, pix);
         valid = pixel_of(rp, pix, x, y);
     }
     if (valid) {
@@ -821,7 +884,7 @@ __device__ __forceinline__ SurfaceOut surface_pathtracer2(const RenderParams& rp
     uint32_t st = lcg_skip(sg.seed, 2u * per_light * sc.n_qlights);
     const float zeta1 = rnd(st), zeta2 = rnd(st);
     const PolarAngle theta = angle_acos(zeta1);
-    const float phi = 2.0f * PT_PIf * zeta2;
+    const float phi = zeta2;  // in turns: 2*pi*zeta2 (:447)
     const vec3 w = normalize(at.normal);
     vec3 a = mk3(0, 1, 0);
     if (1.0f - fabsf(dot(a, w)) <= 1.0f) a = mk3(1, 0, 0);
@@ -885,7 +948,7 @@ __device__ __forceinline__ SurfaceOut surface_pathtracer(const RenderParams& rp,
     const vec3 L_e = P3v(mv.emission), K_s = P3v(mv.specular), K_d = P3v(mv.diffuse);
     const vec3 r = normalize(reflect(-at.wo, at.normal));
     PolarAngle theta = angle_zero();
-    float phi = .0f;
+    float phi = .0f;  // in turns
     vec3 w_i = mk3(.0f);
     vec3 addon_throughput = mk3(1.0f);
     vec3 new_pos = mk3(.0f);  // :517
@@ -952,7 +1015,7 @@ __device__ __forceinline__ SurfaceOut surface_pathtracer(const RenderParams& rp,
         w_i = spherical_dir(theta, phi, u, v, w);
     } else {  // :685-696
         const PolarAngle theta_h_sample = angle_atan((mv.roughness * sqrtf(zeta_1)) / sqrtf(1.0f - zeta_1), rp.semantics != 1);
-        const float phi_h_sample = 2.0f * PT_PIf * zeta_2;
+        const float phi_h_sample = zeta_2;  // in turns: 2*pi*zeta_2 (:687)
         vec3 u_h = mk3(.0f), v_h = mk3(.0f);
         gen_coord_frame(rp.semantics, n, u_h, v_h);
         w_i = normalize(reflect(-at.wo, spherical_dir(theta_h_sample, phi_h_sample, u_h, v_h, n)));
@@ -1081,25 +1144,48 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_surface(RenderParams rp, DevScene
     // ---- the light samples: term + shadow ray each; a term that is exactly zero adds
     // nothing whether or not the ray is blocked, so no ray is queued for it; any other value
     // (NaN included) is stored and its ray queued; k_shadow zeroes the term of an occluded ray
+    // With one or two samples per segment (the usual next-event estimation) the rays wait in
+    // registers and get their queue positions together with the survivor / gather queues,
+    // in a single round of block barriers.
+    const bool few = rp.samples_per_path <= 2u;
+    vec3 f_o[2], f_d[2];
+    float f_tmax[2] = {0.f, 0.f};
+    uint32_t f_slot[2] = {0u, 0u};
+    bool f_need[2] = {false, false};
     if (INTEG != INT_ANALYTICDIRECT) {
         const size_t plane = (size_t)rp.samples_per_path * ps.capacity;
-        for (uint32_t q = 0; q < rp.samples_per_path; ++q) {
-            vec3 sh_o = mk3(0.f), sh_d = mk3(0.f);
-            float sh_tmax = 0.f;
-            bool need_ray = false;
-            uint32_t slot = 0;
-            if (sample) {
-                const vec3 term = light_sample<INTEG>(rp, sc, at, material_of(sc, at.mat), sg.seed, q, sh_o, sh_d, sh_tmax);
-                need_ray = !(term.x == 0.f && term.y == 0.f && term.z == 0.f);
-                slot = contrib_slot(ps, p, q);
-                ps.contrib[slot] = term.x;
-                ps.contrib[slot + plane] = term.y;
-                ps.contrib[slot + 2 * plane] = term.z;
+        if (few) {
+#pragma unroll
+            for (uint32_t q = 0; q < 2u; ++q) {
+                f_o[q] = f_d[q] = mk3(0.f);
+                if (sample && q < rp.samples_per_path) {
+                    const vec3 term = light_sample<INTEG>(rp, sc, at, material_of(sc, at.mat), sg.seed, q, f_o[q], f_d[q], f_tmax[q]);
+                    f_need[q] = !(term.x == 0.f && term.y == 0.f && term.z == 0.f);
+                    f_slot[q] = contrib_slot(ps, p, q);
+                    ps.contrib[f_slot[q]] = term.x;
+                    ps.contrib[f_slot[q] + plane] = term.y;
+                    ps.contrib[f_slot[q] + 2 * plane] = term.z;
+                }
             }
-            const uint32_t at_ = queue_reserve(need_ray, shadow_count);
-            if (need_ray) {
-                ps.sh_o[at_] = make_float4(sh_o.x, sh_o.y, sh_o.z, sh_tmax);
-                ps.sh_d[at_] = make_float4(sh_d.x, sh_d.y, sh_d.z, u2f(slot));
+        } else {
+            for (uint32_t q = 0; q < rp.samples_per_path; ++q) {
+                vec3 sh_o = mk3(0.f), sh_d = mk3(0.f);
+                float sh_tmax = 0.f;
+                bool need_ray = false;
+                uint32_t slot = 0;
+                if (sample) {
+                    const vec3 term = light_sample<INTEG>(rp, sc, at, material_of(sc, at.mat), sg.seed, q, sh_o, sh_d, sh_tmax);
+                    need_ray = !(term.x == 0.f && term.y == 0.f && term.z == 0.f);
+                    slot = contrib_slot(ps, p, q);
+                    ps.contrib[slot] = term.x;
+                    ps.contrib[slot + plane] = term.y;
+                    ps.contrib[slot + 2 * plane] = term.z;
+                }
+                const uint32_t at_ = queue_reserve(need_ray, shadow_count);
+                if (need_ray) {
+                    ps.sh_o[at_] = make_float4(sh_o.x, sh_o.y, sh_o.z, sh_tmax);
+                    ps.sh_d[at_] = make_float4(sh_d.x, sh_d.y, sh_d.z, u2f(slot));
+                }
             }
         }
     }
@@ -1134,18 +1220,31 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_surface(RenderParams rp, DevScene
         alive = !sg.done && sg.depth != rp.max_depth_eff && bounce < rp.bounce_cap;
         if (alive && rp.cull_zero && sg.thr.x == 0.f && sg.thr.y == 0.f && sg.thr.z == 0.f) alive = false;
         if (alive) {
-            const uint32_t pix = p % npix_pad;
-            uint32_t x, y;
+            uint32_t pix, x, y;
+            const uint32_t sample = sample_begin + div_by(p, npix_pad, rp.inv_npix_pad, pix);
             pixel_of(rp, pix, x, y);
             const uint32_t key0 = (x * rp.height + y) * rp.frame_id;
-            const uint32_t seed = segment_seed(rp, key0, sample_begin + p / npix_pad, bounce, segctr, pix);
+            const uint32_t seed = segment_seed(rp, key0, sample, bounce, segctr, pix);
             ps.o_seed[p] = make_float4(sg.o.x, sg.o.y, sg.o.z, u2f(seed));
             ps.d_depth[p] = make_float4(sg.d.x, sg.d.y, sg.d.z, u2f(sg.depth));
             ps.thr[p] = make_float4(sg.thr.x, sg.thr.y, sg.thr.z, u2f(bounce));
         }
     }
-    queue_append(gather, p, gather_queue, gather_count);
-    queue_append(alive, p, next_queue, next_count);
+    if (few) {
+        uint32_t pos[4];
+        queue_reserve4(f_need[0], f_need[1], gather, alive, shadow_count, gather_count, next_count, pos);
+#pragma unroll
+        for (uint32_t q = 0; q < 2u; ++q)
+            if (f_need[q]) {
+                ps.sh_o[pos[q]] = make_float4(f_o[q].x, f_o[q].y, f_o[q].z, f_tmax[q]);
+                ps.sh_d[pos[q]] = make_float4(f_d[q].x, f_d[q].y, f_d[q].z, u2f(f_slot[q]));
+            }
+        if (gather) gather_queue[pos[2]] = p;
+        if (alive) next_queue[pos[3]] = p;
+    } else {
+        queue_append(gather, p, gather_queue, gather_count);
+        queue_append(alive, p, next_queue, next_count);
+    }
 }
 
 // After k_shadow: the radiance of the segments that sampled the lights.

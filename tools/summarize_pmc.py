@@ -25,7 +25,7 @@ def main():
     counters = sorted({c for k in tot for c in tot[k]})
     lines = [f"# {title}", "", "Sums over all dispatches of each kernel (dispatch count in parentheses).", ""]
     for k in sorted(tot, key=lambda k: -tot[k].get("SQ_WAVE_CYCLES", tot[k].get("FETCH_SIZE", 0))):
-        if not any(x in k for x in ("k_extend", "k_trace", "k_shadow", "k_connect", "k_shade", "k_generate", "k_accumulate", "k_compact")):
+        if not any(x in k for x in ("k_extend", "k_trace", "k_shadow", "k_connect", "k_shade", "k_surface", "k_gather", "k_generate", "k_accumulate", "k_compact")):
             continue
         lines.append(f"## `{k}`")
         for c in counters:
