@@ -108,6 +108,45 @@ __device__ __forceinline__ void queue_append(bool keep, uint32_t value, uint32_t
     if (keep) out[at] = value;
 }
 
+// N streams on ONE counter with one atomic per block: all of stream 0 of the block, then
+// all of stream 1, ...  A block that handles N chunks of consecutive queue entries this
+// way keeps the entries in order and issues N times fewer atomics (the same-address
+// atomic rate, about 88 per microsecond, is what bounds the cheap kernels).
+template <int N>
+__device__ __forceinline__ void queue_reserve_streams(const bool keep[N], uint32_t* __restrict__ counter, uint32_t at[N]) {
+    __shared__ uint32_t s_cnt[16][N];
+    __shared__ uint32_t s_base;
+    const uint32_t lane = __lane_id();
+    const uint32_t wave = threadIdx.x >> 6, nwaves = (blockDim.x + 63u) >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    unsigned long long m[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) m[k] = __ballot(keep[k]);
+    __syncthreads();  // the previous call's readers are done
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) s_cnt[wave][k] = (uint32_t)__popcll(m[k]);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (int k = 0; k < N; ++k)
+            for (uint32_t w = 0; w < nwaves; ++w) total += s_cnt[w][k];
+        s_base = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t base = s_base;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        uint32_t b = base;
+        for (uint32_t w = 0; w < nwaves; ++w) {
+            if (w < wave) b += s_cnt[w][k];
+            base += s_cnt[w][k];
+        }
+        at[k] = b + (uint32_t)__popcll(m[k] & lt);
+    }
+}
+
 // The same for four streams at once, with one round of barriers: streams 0 and 1 go to
 // `c01` (all of stream 0 of the block, then all of stream 1), stream 2 to `c2`, stream 3
 // to `c3`.  at[k] receives the position for the streams this thread appends to.
@@ -163,6 +202,8 @@ __device__ __forceinline__ uint32_t segment_seed(const RenderParams& rp, uint32_
 }
 
 // ---------------------------------------------------------------- generate --
+#define GEN_CHUNKS 4   /* chunks of GEN_BLOCK queue entries per block of k_compact_hits */
+
 __global__ __launch_bounds__(GEN_BLOCK) void k_generate(RenderParams rp, PathState ps, uint32_t npix_pad, uint32_t n_paths, uint32_t sample_begin,
                                                     const float* __restrict__ acc, uint32_t* __restrict__ segctr, int seed_L_from_acc,
                                                     uint32_t* __restrict__ queue, uint32_t* __restrict__ qcount) {
@@ -556,21 +597,31 @@ __global__ __launch_bounds__(BLOCK) void k_extend_brute(RenderParams rp, DevScen
 // colour, not scaled by the throughput (Common.cu:13-18).
 __global__ __launch_bounds__(GEN_BLOCK) void k_compact_hits(RenderParams rp, PathState ps, const uint32_t* __restrict__ queue, uint32_t count,
                                                         uint32_t* __restrict__ hit_queue, uint32_t* __restrict__ hit_count) {
-    const uint32_t i = blockIdx.x * GEN_BLOCK + threadIdx.x;
-    bool hit = false;
-    uint32_t p = 0;
-    if (i < count) {
-        p = queue[i];
-        hit = ps.hit_ref[p] != HIT_MISS;
-        if (!hit && (rp.bg[0] != 0.f || rp.bg[1] != 0.f || rp.bg[2] != 0.f)) {
-            float4 L = ps.L[p];
-            L.x += rp.bg[0];
-            L.y += rp.bg[1];
-            L.z += rp.bg[2];
-            ps.L[p] = L;
+    bool hit[GEN_CHUNKS];
+    uint32_t ps_[GEN_CHUNKS], at[GEN_CHUNKS];
+    const bool bg = rp.bg[0] != 0.f || rp.bg[1] != 0.f || rp.bg[2] != 0.f;
+#pragma unroll
+    for (int c = 0; c < GEN_CHUNKS; ++c) {
+        const uint32_t i = (blockIdx.x * GEN_CHUNKS + c) * GEN_BLOCK + threadIdx.x;
+        hit[c] = false;
+        ps_[c] = 0;
+        if (i < count) {
+            const uint32_t p = queue[i];
+            ps_[c] = p;
+            hit[c] = ps.hit_ref[p] != HIT_MISS;
+            if (!hit[c] && bg) {
+                float4 L = ps.L[p];
+                L.x += rp.bg[0];
+                L.y += rp.bg[1];
+                L.z += rp.bg[2];
+                ps.L[p] = L;
+            }
         }
     }
-    queue_append(hit, p, hit_queue, hit_count);
+    queue_reserve_streams<GEN_CHUNKS>(hit, hit_count, at);
+#pragma unroll
+    for (int c = 0; c < GEN_CHUNKS; ++c)
+        if (hit[c]) hit_queue[at[c]] = ps_[c];
 }
 
 // ----------------------------------------------------------- light samples --
@@ -1113,16 +1164,19 @@ __device__ __forceinline__ vec3 gather_radiance(const RenderParams& rp, const De
     return a;
 }
 
+#ifndef SURF_BLOCK
+#define SURF_BLOCK 512   /* two blocks per CU at ~100 registers: one block's barriers hide behind the other */
+#endif
 // One thread per path of the bounce that hit something.
 template <int INTEG>
-__global__ __launch_bounds__(GEN_BLOCK) void k_surface(RenderParams rp, DevScene sc, PathState ps, const uint32_t* __restrict__ queue,
+__global__ __launch_bounds__(SURF_BLOCK) void k_surface(RenderParams rp, DevScene sc, PathState ps, const uint32_t* __restrict__ queue,
                                                        const uint32_t* __restrict__ count_ptr, uint32_t npix_pad, uint32_t sample_begin, uint32_t* __restrict__ segctr,
                                                        uint32_t* __restrict__ next_queue, uint32_t* __restrict__ next_count,
                                                        uint32_t* __restrict__ gather_queue, uint32_t* __restrict__ gather_count,
                                                        uint32_t* __restrict__ shadow_count) {
     const uint32_t count = *count_ptr;  // hits of this bounce, written by k_compact_hits
-    if (blockIdx.x * GEN_BLOCK >= count) return;
-    const uint32_t i = blockIdx.x * GEN_BLOCK + threadIdx.x;
+    if (blockIdx.x * SURF_BLOCK >= count) return;
+    const uint32_t i = blockIdx.x * SURF_BLOCK + threadIdx.x;
     const bool hit = i < count;
     bool sample = false, alive = false, gather = false;
     uint32_t p = 0, bounce = 0;
@@ -1430,7 +1484,7 @@ uint32_t wf_resident_waves(int device) {
 // Queue of the paths whose extension ray hit something; misses end there.
 void wf_compact_hits(hipStream_t s, const RenderParams& rp, const PathState& ps, const uint32_t* queue, uint32_t count, uint32_t* hit_queue, uint32_t* hit_count) {
     if (count == 0) return;
-    hipLaunchKernelGGL(k_compact_hits, dim3(blocks_for(count, GEN_BLOCK)), dim3(GEN_BLOCK), 0, s, rp, ps, queue, count, hit_queue, hit_count);
+    hipLaunchKernelGGL(k_compact_hits, dim3(blocks_for(count, GEN_BLOCK * GEN_CHUNKS)), dim3(GEN_BLOCK), 0, s, rp, ps, queue, count, hit_queue, hit_count);
 }
 
 // `count_ptr` (device) holds the number of queued paths; `max_count` bounds it and sizes the grid.
@@ -1438,7 +1492,7 @@ void wf_surface(hipStream_t s, const RenderParams& rp, const DevScene& sc, const
                 uint32_t max_count, uint32_t npix_pad, uint32_t sample_begin, uint32_t* segctr, uint32_t* next_queue, uint32_t* next_count,
                 uint32_t* gather_queue, uint32_t* gather_count, uint32_t* shadow_count) {
     if (max_count == 0) return;
-    const dim3 g(blocks_for(max_count, GEN_BLOCK)), b(GEN_BLOCK);
+    const dim3 g(blocks_for(max_count, SURF_BLOCK)), b(SURF_BLOCK);
 #define PT_SURFACE(I) hipLaunchKernelGGL(k_surface<I>, g, b, 0, s, rp, sc, ps, queue, count_ptr, npix_pad, sample_begin, segctr, next_queue, next_count, gather_queue, gather_count, shadow_count)
     switch (rp.integrator) {
         case INT_RAYTRACER: PT_SURFACE(INT_RAYTRACER); break;
