@@ -1,0 +1,88 @@
+"""The committed vectors of tests/golden/fixtures.npz (made by tests/golden/make_fixtures.py)
+against the CPU oracle (no GPU needed) and against the HIP path through the C ABI.
+
+Primary-hit records are plain IEEE fp32 arithmetic on both sides: bit-exact.  Radiance sums
+go through libm (powf, acosf, ...): the oracle must reproduce its own vectors to 1e-5
+relative; the GPU to the tolerance of the parity tests (>= 99 % of the pixels within
+1e-3 + 1e-3*|ref|), with equal NaN positions where the committed code produces NaN."""
+import ctypes as C
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+from util import ROOT
+
+spec = importlib.util.spec_from_file_location("make_fixtures", os.path.join(ROOT, "tests", "golden", "make_fixtures.py"))
+mk = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(mk)
+
+FIX = np.load(os.path.join(ROOT, "tests", "golden", "fixtures.npz"), allow_pickle=False)
+RENDERED = [n for n, c in mk.CASES.items() if c[2] is not None]
+
+
+def test_rng_vectors():
+    pairs, tea, rnd, state = mk.rng_vectors()
+    assert np.array_equal(pairs, FIX["tea_in"]) and np.array_equal(tea, FIX["tea_out"])
+    assert np.array_equal(rnd.view(np.uint32), FIX["rnd_seq"].view(np.uint32)) and state == FIX["rnd_state"]
+
+
+@pytest.mark.parametrize("name", [n for n in mk.CASES if n != "dragon"])
+def test_oracle_hits(name):
+    scene, _ = mk.load(name)
+    got = mk.orc.primary_hits(scene)
+    want = FIX[f"hits_{name}"]
+    for f in ("prim", "t", "u", "v"):
+        assert np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)), f
+
+
+def test_oracle_hits_dragon():
+    scene, _ = mk.load("dragon")
+    got = mk.orc.primary_hits(scene, use_bvh=1)
+    want = FIX["hits_dragon"]
+    for f in ("prim", "t", "u", "v"):
+        assert np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)), f
+
+
+@pytest.mark.parametrize("name", RENDERED)
+def test_oracle_sums(name):
+    scene, opts = mk.load(name)
+    sums, _, st = mk.orc.render(scene, **opts)
+    want = FIX[f"sums_{name}"]
+    assert np.array_equal(np.isnan(sums), np.isnan(want))
+    assert np.allclose(sums, want, rtol=1e-5, atol=1e-6, equal_nan=True)
+    assert [st.paths, st.extension_rays, st.shadow_rays] == FIX[f"rays_{name}"].tolist()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(mk.CASES))
+def test_gpu_hits(name):
+    from pathtracer_amd import Renderer
+    scene, _ = mk.load(name)
+    r = Renderer(scene)
+    got = r.primary_hits()
+    r.close()
+    want = FIX[f"hits_{name}"]
+    for f in ("prim", "t", "u", "v"):
+        assert np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)), f
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", RENDERED)
+def test_gpu_sums(name):
+    from pathtracer_amd import Renderer, _ffi
+    scene, opts = mk.load(name)
+    options = {_ffi.OPT_SEMANTICS: opts.get("semantics", 0), _ffi.OPT_SEEDING: opts.get("seeding", 0), _ffi.OPT_BOUNCE_CAP: opts.get("bounce_cap", 1024)}
+    r = Renderer(scene, options=options)
+    r.run()
+    got, st = r.sums(), r.stats()
+    r.close()
+    want = FIX[f"sums_{name}"]
+    paths, ext, shadow = (int(x) for x in FIX[f"rays_{name}"])
+    assert st.paths == paths
+    if np.isnan(want).any():
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+    ok = np.isclose(got, want, rtol=1e-3, atol=1e-3, equal_nan=True).all(axis=2)
+    assert ok.mean() >= 0.99, ok.mean()
+    assert abs(int(st.extension_rays) - ext) <= 0.01 * ext + 16
