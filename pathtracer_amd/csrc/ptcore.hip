@@ -341,7 +341,7 @@ int runBounces(ptc_context* ctx, const RenderParams& rp, const DevScene& sc, uin
                 wf_shadow(ctx->stream, rp, sc, ctx->ps, grp + 2, (uint64_t)count * S, grp + 4, ctx->resident_waves, ctx->count_trav != 0, ctx->counters, ctx->counters + 4);
             }
             Timed t(ctx, 2);
-            wf_gather(ctx->stream, rp, sc, ctx->ps, ctx->gatherq, grp + 5, count);
+            wf_gather(ctx->stream, rp, sc, ctx->ps, ctx->hitq, ctx->gatherq, grp + 5, count);
             ctx->stats.connect_launches++;
         }
         ctx->stats.shade_launches++;

@@ -10,9 +10,23 @@
 #include "device_scene.h"
 #include "intersect.h"
 
+// powf(x, y) for the non-negative bases of the Phong terms (a clamped cosine, a uniform
+// random number), as exp2(y * log2(x)) on the hardware's 1-ulp log2 / exp2 units.  The
+// error is that of the exponent, |y * log2 x| * 2^-23, i.e. below 2e-6 relative wherever
+// the result is above 1e-6; libm's powf is several times the cost of everything else in
+// the Phong branch.  PT_LIBM_POWF restores the libm call.
+__device__ __forceinline__ float pow_pos(float x, float y) {
+#ifdef PT_LIBM_POWF
+    return powf(x, y);
+#else
+    if (y == 0.0f) return 1.0f;  // powf(x, 0) is 1 for every x
+    return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));  // v_exp_f32, v_log_f32
+#endif
+}
+
 // RayTracer.cu:259-263
 __device__ __forceinline__ vec3 phong_brdf(vec3 wi, vec3 reflect_vec, float shininess, vec3 diffuse, vec3 specular) {
-    return (diffuse / PT_PIf) + (specular * ((shininess + 2.0f) / (2.0f * PT_PIf)) * powf(fmaxf(dot(reflect_vec, wi), .0f), shininess));
+    return (diffuse / PT_PIf) + (specular * ((shininess + 2.0f) / (2.0f * PT_PIf)) * pow_pos(fmaxf(dot(reflect_vec, wi), .0f), shininess));
 }
 
 // The reference evaluates its GGX terms through chains of libm calls on an angle:
@@ -118,7 +132,7 @@ __device__ __forceinline__ void compute_polar_angles(int semantics, uint32_t sam
             if (z0 > t)
                 theta = angle_acos(sqrtf(z1));
             else
-                theta = angle_acos(powf(z1, (1.0f / (shininess + 1.0f))));
+                theta = angle_acos(pow_pos(z1, (1.0f / (shininess + 1.0f))));
             break;
         default:
             break;

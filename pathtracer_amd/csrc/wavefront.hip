@@ -629,9 +629,12 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_compact_hits(RenderParams rp, Pat
 __device__ __forceinline__ const PtcMaterialValue& material_of(const DevScene& sc, uint32_t mat) { return sc.materials[mat & ~MAT_LIGHT_BIT]; }
 __device__ __forceinline__ bool is_light(uint32_t mat) { return (mat & MAT_LIGHT_BIT) != 0u; }
 
-// Position of light sample q's term for path p: three planes of
-// samples_per_path * capacity floats.
-__device__ __forceinline__ uint32_t contrib_slot(const PathState& ps, uint32_t p, uint32_t q) { return q * ps.capacity + p; }
+// Position of light sample q's term for the segment at position `seg` of the bounce's hit
+// queue: three planes of samples_per_path * capacity floats.  (Everything that lives for
+// one segment only -- these terms, the gather records -- is indexed by the hit-queue
+// position, which is dense, and not by the path number, whose live entries thin out with
+// every bounce.)
+__device__ __forceinline__ uint32_t contrib_slot(const PathState& ps, uint32_t seg, uint32_t q) { return q * ps.capacity + seg; }
 
 // Does the integrator sample the lights at this hit?
 template <int INTEG>
@@ -664,7 +667,7 @@ __device__ __forceinline__ vec3 light_sample(const RenderParams& rp, const DevSc
         sh_o = at.P + sh_d * cf.epsilon;
         const vec3 H = normalize(sh_d + at.wo);
         vec3 I = P3v(mv.diffuse) * fmaxf(dot(at.normal, sh_d), 0);
-        I += P3v(mv.specular) * powf(fmaxf(dot(at.normal, H), 0), mv.shininess);
+        I += P3v(mv.specular) * pow_pos(fmaxf(dot(at.normal, H), 0), mv.shininess);
         if (q < sc.n_plights) {
             const float lightDist = sh_tmax;
             const float att = dot(P3v(sc.plights[q].attenuation), mk3(1, lightDist, lightDist * lightDist));
@@ -702,7 +705,7 @@ __device__ __forceinline__ vec3 light_sample(const RenderParams& rp, const DevSc
         const vec3 wdir = normalize(light_pos - sh_o);
         const vec3 f_brdf = (P3v(mv.diffuse) / PT_PIf) +
                             (P3v(mv.specular) * ((mv.shininess + 2.0f) / (2.0f * PT_PIf)) *
-                             powf(fmaxf(dot(normalize(reflect(-at.wo, at.normal)), wdir), .0f), mv.shininess));
+                             pow_pos(fmaxf(dot(normalize(reflect(-at.wo, at.normal)), wdir), .0f), mv.shininess));
         const vec3 n_light = normalize(cross(qf.ab, qf.ac));
         const float R = length(sh_o - light_pos);
         const float G = (1.0f / powf(R, 2.0f)) * fmaxf(dot(at.normal, normalize(light_pos - sh_o)), .0f) *
@@ -834,16 +837,16 @@ struct SurfaceOut {
     bool gather;
 };
 
-__device__ __forceinline__ vec3 contrib_at(const RenderParams& rp, const PathState& ps, uint32_t p, uint32_t q) {
+__device__ __forceinline__ vec3 contrib_at(const RenderParams& rp, const PathState& ps, uint32_t seg, uint32_t q) {
     const size_t plane = (size_t)rp.samples_per_path * ps.capacity;
-    const float* c = ps.contrib + contrib_slot(ps, p, q);
+    const float* c = ps.contrib + contrib_slot(ps, seg, q);
     return mk3(c[0], c[plane], c[2 * plane]);
 }
 
 // Sum of the light-sample terms of quad light k in loop order.
-__device__ __forceinline__ vec3 light_sum(const RenderParams& rp, const PathState& ps, uint32_t p, uint32_t k, uint32_t per_light) {
+__device__ __forceinline__ vec3 light_sum(const RenderParams& rp, const PathState& ps, uint32_t seg, uint32_t k, uint32_t per_light) {
     vec3 s = mk3(.0f);
-    for (uint32_t r = 0; r < per_light; ++r) s += contrib_at(rp, ps, p, k * per_light + r);
+    for (uint32_t r = 0; r < per_light; ++r) s += contrib_at(rp, ps, seg, k * per_light + r);
     return s;
 }
 
@@ -868,10 +871,10 @@ __device__ __forceinline__ SurfaceOut surface_raytracer(const RenderParams& rp, 
     }
     return SurfaceOut{a, lights};
 }
-__device__ __forceinline__ vec3 gather_raytracer(const RenderParams& rp, const DevScene& sc, const PathState& ps, uint32_t p, vec3 a, vec3 thr) {
+__device__ __forceinline__ vec3 gather_raytracer(const RenderParams& rp, const DevScene& sc, const PathState& ps, uint32_t seg, vec3 a, vec3 thr) {
     vec3 result = a;
     const uint32_t nl = sc.n_plights + sc.n_dlights;
-    for (uint32_t q = 0; q < nl; ++q) result += contrib_at(rp, ps, p, q);  // occluded lights left 0
+    for (uint32_t q = 0; q < nl; ++q) result += contrib_at(rp, ps, seg, q);  // occluded lights left 0
     return result * thr;
 }
 
@@ -912,12 +915,12 @@ __device__ __forceinline__ SurfaceOut surface_direct(const RenderParams& rp, con
     }
     return SurfaceOut{result, sc.n_qlights != 0u};
 }
-__device__ __forceinline__ vec3 gather_direct(const RenderParams& rp, const DevScene& sc, const PathState& ps, uint32_t p, vec3 a) {
+__device__ __forceinline__ vec3 gather_direct(const RenderParams& rp, const DevScene& sc, const PathState& ps, uint32_t seg, vec3 a) {
     vec3 result = a;
     const uint32_t per_light = rp.root_light_samples * rp.root_light_samples;
     for (uint32_t k = 0; k < sc.n_qlights; ++k) {
         const float area = fabsf(quad_area(sc.qlights[k], false));
-        result += P3v(sc.qlights[k].color) * light_sum(rp, ps, p, k, per_light) * (area / (float)rp.light_samples);
+        result += P3v(sc.qlights[k].color) * light_sum(rp, ps, seg, k, per_light) * (area / (float)rp.light_samples);
     }
     return result;
 }
@@ -963,12 +966,12 @@ __device__ __forceinline__ SurfaceOut surface_pathtracer2(const RenderParams& rp
     sg.depth++;
     return SurfaceOut{radiance, true};
 }
-__device__ __forceinline__ vec3 gather_pathtracer2(const RenderParams& rp, const DevScene& sc, const PathState& ps, uint32_t p, vec3 a, vec3 thr) {
+__device__ __forceinline__ vec3 gather_pathtracer2(const RenderParams& rp, const DevScene& sc, const PathState& ps, uint32_t seg, vec3 a, vec3 thr) {
     const uint32_t per_light = rp.root_light_samples * rp.root_light_samples;
     vec3 L_d = mk3(.0f);
     for (uint32_t k = 0; k < sc.n_qlights; ++k) {
         const float area = fabsf(quad_area(sc.qlights[k], true));
-        L_d += P3v(sc.qlights[k].color) * (area / (float)rp.light_samples) * light_sum(rp, ps, p, k, per_light);
+        L_d += P3v(sc.qlights[k].color) * (area / (float)rp.light_samples) * light_sum(rp, ps, seg, k, per_light);
     }
     vec3 radiance = a;
     radiance += L_d * thr;
@@ -1078,12 +1081,12 @@ __device__ __forceinline__ SurfaceOut surface_pathtracer(const RenderParams& rp,
     float pdf = 1.0f;
     switch (rp.sampling_method) {  // :811-897
         case PTC_HEMISPHERE_SAMPLING:
-            f_brdf = (P3v(mv.diffuse) / PT_PIf) + (P3v(mv.specular) * ((mv.shininess + 2.0f) / (2.0f * PT_PIf)) * powf(fmaxf(dot(r, w_i), .0f), mv.shininess));
+            f_brdf = (P3v(mv.diffuse) / PT_PIf) + (P3v(mv.specular) * ((mv.shininess + 2.0f) / (2.0f * PT_PIf)) * pow_pos(fmaxf(dot(r, w_i), .0f), mv.shininess));
             pdf = 1.0f / (2.0f * PT_PIf);
             addon_throughput = (f_brdf * fmaxf(dot(n, w_i), .0f) * (1.0f / pdf));
             break;
         case PTC_COSINE_SAMPLING:
-            f_brdf = (P3v(mv.diffuse) / PT_PIf) + (P3v(mv.specular) * ((mv.shininess + 2.0f) / (2.0f * PT_PIf)) * powf(fmaxf(dot(r, w_i), .0f), mv.shininess));
+            f_brdf = (P3v(mv.diffuse) / PT_PIf) + (P3v(mv.specular) * ((mv.shininess + 2.0f) / (2.0f * PT_PIf)) * pow_pos(fmaxf(dot(r, w_i), .0f), mv.shininess));
             pdf = fmaxf(dot(n, w_i), .0f) / (PT_PIf);
             addon_throughput = (f_brdf)*fmaxf(dot(n, w_i), .0f) * (1.0f / pdf);
             break;
@@ -1092,7 +1095,7 @@ __device__ __forceinline__ SurfaceOut surface_pathtracer(const RenderParams& rp,
             // again; they cannot change the payload and are not traced.
             if (mv.brdf_type == PTC_MOD_PHONG) {
                 f_brdf = phong_brdf(w_i, r, mv.shininess, K_d, K_s);
-                pdf = ((1.0f - t) * (dot(n, w_i) / PT_PIf)) + t * ((mv.shininess + 1.0f) / (2.0f * PT_PIf)) * powf(fmaxf(dot(r, w_i), .0f), mv.shininess);
+                pdf = ((1.0f - t) * (dot(n, w_i) / PT_PIf)) + t * ((mv.shininess + 1.0f) / (2.0f * PT_PIf)) * pow_pos(fmaxf(dot(r, w_i), .0f), mv.shininess);
             } else {
                 const float wi_dot_n = dot(w_i, n);
                 const float wo_dot_n = dot(at.wo, n);
@@ -1130,12 +1133,12 @@ __device__ __forceinline__ SurfaceOut surface_pathtracer(const RenderParams& rp,
     return out;
 }
 
-__device__ __forceinline__ vec3 gather_pathtracer(const RenderParams& rp, const DevScene& sc, const PathState& ps, uint32_t p, vec3 a, vec3 thr, bool with_Le) {
+__device__ __forceinline__ vec3 gather_pathtracer(const RenderParams& rp, const DevScene& sc, const PathState& ps, uint32_t seg, vec3 a, vec3 thr, bool with_Le) {
     const PtcConfig& cf = rp.cf;
     const uint32_t per_light = rp.root_light_samples * rp.root_light_samples;
     vec3 L_d = mk3(.0f);
     for (uint32_t k = 0; k < sc.n_qlights; ++k) {  // :702-800
-        const vec3 sampled_result = light_sum(rp, ps, p, k, per_light);
+        const vec3 sampled_result = light_sum(rp, ps, seg, k, per_light);
         const float area = quad_area(sc.qlights[k], false);
         if (cf.next_event_est == PTC_NEE_MIS) {
             // :782-794 as written: pdf_lights_k, D and h are never assigned, so
@@ -1156,11 +1159,11 @@ __device__ __forceinline__ vec3 gather_pathtracer(const RenderParams& rp, const 
 }
 
 template <int INTEG>
-__device__ __forceinline__ vec3 gather_radiance(const RenderParams& rp, const DevScene& sc, const PathState& ps, uint32_t p, vec3 a, vec3 thr, bool with_Le) {
-    if (INTEG == INT_RAYTRACER) return gather_raytracer(rp, sc, ps, p, a, thr);
-    if (INTEG == INT_DIRECT) return gather_direct(rp, sc, ps, p, a);
-    if (INTEG == INT_PATHTRACER2) return gather_pathtracer2(rp, sc, ps, p, a, thr);
-    if (INTEG == INT_PATHTRACER) return gather_pathtracer(rp, sc, ps, p, a, thr, with_Le);
+__device__ __forceinline__ vec3 gather_radiance(const RenderParams& rp, const DevScene& sc, const PathState& ps, uint32_t seg, vec3 a, vec3 thr, bool with_Le) {
+    if (INTEG == INT_RAYTRACER) return gather_raytracer(rp, sc, ps, seg, a, thr);
+    if (INTEG == INT_DIRECT) return gather_direct(rp, sc, ps, seg, a);
+    if (INTEG == INT_PATHTRACER2) return gather_pathtracer2(rp, sc, ps, seg, a, thr);
+    if (INTEG == INT_PATHTRACER) return gather_pathtracer(rp, sc, ps, seg, a, thr, with_Le);
     return a;
 }
 
@@ -1215,7 +1218,7 @@ __global__ __launch_bounds__(SURF_BLOCK) void k_surface(RenderParams rp, DevScen
                 if (sample && q < rp.samples_per_path) {
                     const vec3 term = light_sample<INTEG>(rp, sc, at, material_of(sc, at.mat), sg.seed, q, f_o[q], f_d[q], f_tmax[q]);
                     f_need[q] = !(term.x == 0.f && term.y == 0.f && term.z == 0.f);
-                    f_slot[q] = contrib_slot(ps, p, q);
+                    f_slot[q] = contrib_slot(ps, i, q);
                     ps.contrib[f_slot[q]] = term.x;
                     ps.contrib[f_slot[q] + plane] = term.y;
                     ps.contrib[f_slot[q] + 2 * plane] = term.z;
@@ -1230,7 +1233,7 @@ __global__ __launch_bounds__(SURF_BLOCK) void k_surface(RenderParams rp, DevScen
                 if (sample) {
                     const vec3 term = light_sample<INTEG>(rp, sc, at, material_of(sc, at.mat), sg.seed, q, sh_o, sh_d, sh_tmax);
                     need_ray = !(term.x == 0.f && term.y == 0.f && term.z == 0.f);
-                    slot = contrib_slot(ps, p, q);
+                    slot = contrib_slot(ps, i, q);
                     ps.contrib[slot] = term.x;
                     ps.contrib[slot + plane] = term.y;
                     ps.contrib[slot + 2 * plane] = term.z;
@@ -1256,13 +1259,13 @@ __global__ __launch_bounds__(SURF_BLOCK) void k_surface(RenderParams rp, DevScen
         gather = out.gather && sample;
         if (gather) {
             // w: does the first-hit rule of pathTracer include the emission (:900-903)
-            ps.g_a[p] = make_float4(out.a.x, out.a.y, out.a.z, u2f((!rp.cf.next_event_est || depth_before == 0u) ? 1u : 0u));
-            ps.g_thr[p] = make_float4(thr_before.x, thr_before.y, thr_before.z, 0.f);
+            ps.g_a[i] = make_float4(out.a.x, out.a.y, out.a.z, u2f((!rp.cf.next_event_est || depth_before == 0u) ? 1u : 0u));
+            ps.g_thr[i] = make_float4(thr_before.x, thr_before.y, thr_before.z, 0.f);
         } else {
             // gather wanted but there is not a single light sample (lightsamples 0): the same
             // formulas over zero terms, here
             vec3 radiance = out.a;
-            if (out.gather) radiance = gather_radiance<INTEG>(rp, sc, ps, p, out.a, thr_before, !rp.cf.next_event_est || depth_before == 0u);
+            if (out.gather) radiance = gather_radiance<INTEG>(rp, sc, ps, i, out.a, thr_before, !rp.cf.next_event_est || depth_before == 0u);
             float4 L = ps.L[p];
             L.x += radiance.x;  // PinholeCamera.cu:61
             L.y += radiance.y;
@@ -1293,24 +1296,25 @@ __global__ __launch_bounds__(SURF_BLOCK) void k_surface(RenderParams rp, DevScen
                 ps.sh_o[pos[q]] = make_float4(f_o[q].x, f_o[q].y, f_o[q].z, f_tmax[q]);
                 ps.sh_d[pos[q]] = make_float4(f_d[q].x, f_d[q].y, f_d[q].z, u2f(f_slot[q]));
             }
-        if (gather) gather_queue[pos[2]] = p;
+        if (gather) gather_queue[pos[2]] = i;
         if (alive) next_queue[pos[3]] = p;
     } else {
-        queue_append(gather, p, gather_queue, gather_count);
+        queue_append(gather, i, gather_queue, gather_count);
         queue_append(alive, p, next_queue, next_count);
     }
 }
 
 // After k_shadow: the radiance of the segments that sampled the lights.
 template <int INTEG>
-__global__ __launch_bounds__(GEN_BLOCK) void k_gather(RenderParams rp, DevScene sc, PathState ps, const uint32_t* __restrict__ gather_queue,
-                                                      const uint32_t* __restrict__ gather_count) {
+__global__ __launch_bounds__(GEN_BLOCK) void k_gather(RenderParams rp, DevScene sc, PathState ps, const uint32_t* __restrict__ hit_queue,
+                                                      const uint32_t* __restrict__ gather_queue, const uint32_t* __restrict__ gather_count) {
     const uint32_t i = blockIdx.x * GEN_BLOCK + threadIdx.x;
     if (i >= *gather_count) return;
-    const uint32_t p = gather_queue[i];
-    const float4 a4 = ps.g_a[p], t4 = ps.g_thr[p];
+    const uint32_t seg = gather_queue[i];  // position in the hit queue
+    const uint32_t p = hit_queue[seg];
+    const float4 a4 = ps.g_a[seg], t4 = ps.g_thr[seg];
     const vec3 a = mk3(a4.x, a4.y, a4.z), thr = mk3(t4.x, t4.y, t4.z);
-    const vec3 radiance = gather_radiance<INTEG>(rp, sc, ps, p, a, thr, f2u(a4.w) != 0u);
+    const vec3 radiance = gather_radiance<INTEG>(rp, sc, ps, seg, a, thr, f2u(a4.w) != 0u);
     float4 L = ps.L[p];
     L.x += radiance.x;  // PinholeCamera.cu:61
     L.y += radiance.y;
@@ -1506,15 +1510,15 @@ void wf_surface(hipStream_t s, const RenderParams& rp, const DevScene& sc, const
 }
 
 // `gather_count` (device) holds the number of queued paths; `max_count` bounds it and sizes the grid.
-void wf_gather(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* gather_queue, const uint32_t* gather_count,
-               uint32_t max_count) {
+void wf_gather(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* hit_queue, const uint32_t* gather_queue,
+               const uint32_t* gather_count, uint32_t max_count) {
     if (max_count == 0) return;
     const dim3 g(blocks_for(max_count, GEN_BLOCK)), b(GEN_BLOCK);
     switch (rp.integrator) {
-        case INT_RAYTRACER: hipLaunchKernelGGL(k_gather<INT_RAYTRACER>, g, b, 0, s, rp, sc, ps, gather_queue, gather_count); break;
-        case INT_DIRECT: hipLaunchKernelGGL(k_gather<INT_DIRECT>, g, b, 0, s, rp, sc, ps, gather_queue, gather_count); break;
-        case INT_PATHTRACER: hipLaunchKernelGGL(k_gather<INT_PATHTRACER>, g, b, 0, s, rp, sc, ps, gather_queue, gather_count); break;
-        case INT_PATHTRACER2: hipLaunchKernelGGL(k_gather<INT_PATHTRACER2>, g, b, 0, s, rp, sc, ps, gather_queue, gather_count); break;
+        case INT_RAYTRACER: hipLaunchKernelGGL(k_gather<INT_RAYTRACER>, g, b, 0, s, rp, sc, ps, hit_queue, gather_queue, gather_count); break;
+        case INT_DIRECT: hipLaunchKernelGGL(k_gather<INT_DIRECT>, g, b, 0, s, rp, sc, ps, hit_queue, gather_queue, gather_count); break;
+        case INT_PATHTRACER: hipLaunchKernelGGL(k_gather<INT_PATHTRACER>, g, b, 0, s, rp, sc, ps, hit_queue, gather_queue, gather_count); break;
+        case INT_PATHTRACER2: hipLaunchKernelGGL(k_gather<INT_PATHTRACER2>, g, b, 0, s, rp, sc, ps, hit_queue, gather_queue, gather_count); break;
         default: break;
     }
 }
