@@ -146,7 +146,7 @@ enum {
      * contribution is radiance*throughput, RayTracer.cu:918). Default 1. */
     PTC_OPT_CULL_ZERO = 4,
     /* Maximum camera paths in flight per wavefront batch (rounded to whole
-     * samples over the image). Default 67108864 (about 11 GB of path state). */
+     * samples over the image). Default 67108864 (about 16 GB of path state with two light samples per segment). */
     PTC_OPT_BATCH_PATHS = 5,
     /* 1 = bracket every kernel class with HIP events and sum the times. */
     PTC_OPT_PROFILE = 6,

@@ -110,11 +110,20 @@ struct RenderParams {
     uint32_t tune_refill, tune_mode, tune_shadow, tune_chunk;
 };
 
-// Per-path state, structure of arrays, `capacity` entries each.
+// Path state.  The LIVE paths of a bounce are kept packed in entries [0, count) of
+// o_seed / d_depth / thr / pid / hit_*; the surface kernel writes the survivors, packed
+// again, to the `*_next` arrays and the host swaps the two sets.  (With the state indexed by
+// path number instead, the live entries thin out from bounce to bounce and every 16-byte
+// access drags a mostly dead cache line along.)  `L` is per path number.
 struct PathState {
     float4* o_seed;    // origin.xyz, seed of the coming segment (bits)
     float4* d_depth;   // direction.xyz, depth (bits)
     float4* thr;       // throughput.xyz, segment number within the path (bits)
+    uint32_t* pid;     // path number: sample-in-batch * padded pixel count + padded pixel number
+    float4* o_seed_next;
+    float4* d_depth_next;
+    float4* thr_next;
+    uint32_t* pid_next;
     float4* L;         // radiance accumulated by this path
     float4* g_a;       // segments waiting for their light terms: constant part, emission flag (bits)
     float4* g_thr;     //   throughput before the segment

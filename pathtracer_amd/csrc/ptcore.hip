@@ -70,7 +70,6 @@ struct ptc_context {
     // wavefront state
     PathState ps{};
     uint32_t contrib_samples = 0;
-    uint32_t* queue[2] = {nullptr, nullptr};    // live paths of this / the next bounce
     uint32_t* hitq = nullptr;                   // paths of this bounce that hit something
     uint32_t* gatherq = nullptr;                // segments of this bounce whose radiance waits for the light terms
     uint32_t* qcount = nullptr;                 // two groups {hit, next, shadow, extend work, shadow work} used alternately, [16] generate
@@ -129,10 +128,11 @@ void freeTargets(ptc_context* c) {
 
 void freePaths(ptc_context* c) {
     for (void* p : {(void*)c->ps.o_seed, (void*)c->ps.d_depth, (void*)c->ps.thr, (void*)c->ps.L, (void*)c->ps.g_a, (void*)c->ps.g_thr, (void*)c->ps.hit_t, (void*)c->ps.hit_ref,
-                    (void*)c->ps.contrib, (void*)c->ps.sh_o, (void*)c->ps.sh_d, (void*)c->queue[0], (void*)c->queue[1], (void*)c->hitq, (void*)c->gatherq})
+                    (void*)c->ps.contrib, (void*)c->ps.sh_o, (void*)c->ps.sh_d, (void*)c->ps.pid, (void*)c->ps.o_seed_next, (void*)c->ps.d_depth_next,
+                    (void*)c->ps.thr_next, (void*)c->ps.pid_next, (void*)c->hitq, (void*)c->gatherq})
         if (p) (void)hipFree(p);
     c->ps = PathState{};
-    c->queue[0] = c->queue[1] = c->hitq = c->gatherq = nullptr;
+    c->hitq = c->gatherq = nullptr;
     c->contrib_samples = 0;
 }
 
@@ -176,8 +176,11 @@ int ensurePaths(ptc_context* ctx, uint32_t capacity, uint32_t contrib_samples) {
     CHK(hipMalloc((void**)&ctx->ps.contrib, std::max<size_t>((size_t)capacity * contrib_samples * 3, 1) * sizeof(float)));
     CHK(hipMalloc((void**)&ctx->ps.sh_o, std::max<size_t>((size_t)capacity * contrib_samples, 1) * sizeof(float4)));
     CHK(hipMalloc((void**)&ctx->ps.sh_d, std::max<size_t>((size_t)capacity * contrib_samples, 1) * sizeof(float4)));
-    CHK(hipMalloc((void**)&ctx->queue[0], (size_t)capacity * sizeof(uint32_t)));
-    CHK(hipMalloc((void**)&ctx->queue[1], (size_t)capacity * sizeof(uint32_t)));
+    CHK(hipMalloc((void**)&ctx->ps.pid, (size_t)capacity * sizeof(uint32_t)));
+    CHK(hipMalloc((void**)&ctx->ps.o_seed_next, (size_t)capacity * sizeof(float4)));
+    CHK(hipMalloc((void**)&ctx->ps.d_depth_next, (size_t)capacity * sizeof(float4)));
+    CHK(hipMalloc((void**)&ctx->ps.thr_next, (size_t)capacity * sizeof(float4)));
+    CHK(hipMalloc((void**)&ctx->ps.pid_next, (size_t)capacity * sizeof(uint32_t)));
     CHK(hipMalloc((void**)&ctx->hitq, (size_t)capacity * sizeof(uint32_t)));
     CHK(hipMalloc((void**)&ctx->gatherq, (size_t)capacity * sizeof(uint32_t)));
     ctx->ps.capacity = capacity;
@@ -307,14 +310,13 @@ int uploadLights(ptc_context* ctx) {
 #define N_COUNTERS 8
 #define N_QCOUNT 20
 
-// Trace every bounce of the paths in queue[0] (count0 of them).  Per bounce:
+// Trace every bounce of the count0 paths k_generate left in the path state.  Per bounce:
 // extend, hit compaction, surface (light samples + shadow rays, next direction,
 // survivors -> next queue), shadow, gather (radiance of the segments that sampled the lights).  Queue
 // lengths stay on the device; the grids are sized by the bounce's path count; the next
 // queue's length is the one word read back.
 int runBounces(ptc_context* ctx, const RenderParams& rp, const DevScene& sc, uint32_t count0, uint32_t sample_begin) {
     uint32_t count = count0;
-    int cur = 0;
     uint32_t bounce = 0;
     const uint32_t S = rp.samples_per_path;
     while (count > 0) {
@@ -322,17 +324,17 @@ int runBounces(ptc_context* ctx, const RenderParams& rp, const DevScene& sc, uin
         CHK(hipMemsetAsync(grp, 0, 6 * sizeof(uint32_t), ctx->stream));
         {
             Timed t(ctx, 0);
-            wf_extend(ctx->stream, rp, sc, ctx->ps, ctx->queue[cur], count, grp + 3, ctx->resident_waves, bounce == 0, ctx->count_trav != 0, ctx->counters);
+            wf_extend(ctx->stream, rp, sc, ctx->ps, count, grp + 3, ctx->resident_waves, bounce == 0, ctx->count_trav != 0, ctx->counters);
         }
         ctx->stats.extension_rays += count;
         ctx->stats.extend_launches++;
         {
             Timed t(ctx, 3);
-            wf_compact_hits(ctx->stream, rp, ctx->ps, ctx->queue[cur], count, ctx->hitq, grp);
+            wf_compact_hits(ctx->stream, rp, ctx->ps, count, ctx->hitq, grp);
         }
         {
             Timed t(ctx, 2);
-            wf_surface(ctx->stream, rp, sc, ctx->ps, ctx->hitq, grp, count, ctx->npix_pad, sample_begin, ctx->segctr, ctx->queue[cur ^ 1], grp + 1, ctx->gatherq,
+            wf_surface(ctx->stream, rp, sc, ctx->ps, ctx->hitq, grp, count, ctx->npix_pad, sample_begin, ctx->segctr, grp + 1, ctx->gatherq,
                        grp + 5, grp + 2);
         }
         if (S) {
@@ -341,7 +343,7 @@ int runBounces(ptc_context* ctx, const RenderParams& rp, const DevScene& sc, uin
                 wf_shadow(ctx->stream, rp, sc, ctx->ps, grp + 2, (uint64_t)count * S, grp + 4, ctx->resident_waves, ctx->count_trav != 0, ctx->counters, ctx->counters + 4);
             }
             Timed t(ctx, 2);
-            wf_gather(ctx->stream, rp, sc, ctx->ps, ctx->hitq, ctx->gatherq, grp + 5, count);
+            wf_gather(ctx->stream, rp, sc, ctx->ps, ctx->gatherq, grp + 5, count);
             ctx->stats.connect_launches++;
         }
         ctx->stats.shade_launches++;
@@ -357,7 +359,11 @@ int runBounces(ptc_context* ctx, const RenderParams& rp, const DevScene& sc, uin
                     count, q[0], q[2], q[1], h[0], h[1], h[2], h[3]);
         }
         count = *ctx->h_count;
-        cur ^= 1;
+        // the survivors' packed state becomes the current one
+        std::swap(ctx->ps.o_seed, ctx->ps.o_seed_next);
+        std::swap(ctx->ps.d_depth, ctx->ps.d_depth_next);
+        std::swap(ctx->ps.thr, ctx->ps.thr_next);
+        std::swap(ctx->ps.pid, ctx->ps.pid_next);
         ++bounce;
     }
     return PTC_OK;
@@ -399,7 +405,7 @@ int renderRange(ptc_context* ctx, int frame_id, uint32_t w, uint32_t h, int32_t 
         CHK(hipMemsetAsync(ctx->qcount + 16, 0, sizeof(uint32_t), ctx->stream));
         {
             Timed t(ctx, 3);
-            wf_generate(ctx->stream, rp, ctx->ps, ctx->npix_pad, n_paths, (uint32_t)ja, ctx->acc, ctx->segctr, seedL, ctx->queue[0], ctx->qcount + 16);
+            wf_generate(ctx->stream, rp, ctx->ps, ctx->npix_pad, n_paths, (uint32_t)ja, ctx->acc, ctx->segctr, seedL, ctx->qcount + 16);
         }
         CHK(hipMemcpyAsync(ctx->h_count, ctx->qcount + 16, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         CHK(hipStreamSynchronize(ctx->stream));
@@ -669,11 +675,11 @@ int ptc_primary_hits(ptc_context* ctx, uint32_t width, uint32_t height, PtcHitRe
     const DevScene sc = deviceScene(ctx);
     CHK(hipMemsetAsync(ctx->qcount, 0, N_QCOUNT * sizeof(uint32_t), ctx->stream));
     CHK(hipMemsetAsync(ctx->ps.hit_ref, 0xFF, (size_t)ctx->npix_pad * sizeof(int32_t), ctx->stream));  // HIT_MISS
-    wf_generate(ctx->stream, rp, ctx->ps, ctx->npix_pad, ctx->npix_pad, 0u, ctx->acc, ctx->segctr, 0, ctx->queue[0], ctx->qcount + 16);
+    wf_generate(ctx->stream, rp, ctx->ps, ctx->npix_pad, ctx->npix_pad, 0u, ctx->acc, ctx->segctr, 0, ctx->qcount + 16);
     CHK(hipMemcpyAsync(ctx->h_count, ctx->qcount + 16, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     CHK(hipStreamSynchronize(ctx->stream));
-    wf_extend(ctx->stream, rp, sc, ctx->ps, ctx->queue[0], *ctx->h_count, ctx->qcount + 3, ctx->resident_waves, true, false, ctx->counters);
-    wf_hit_records(ctx->stream, rp, sc, ctx->ps, ctx->npix_pad, ctx->d_hits);
+    wf_extend(ctx->stream, rp, sc, ctx->ps, *ctx->h_count, ctx->qcount + 3, ctx->resident_waves, true, false, ctx->counters);
+    wf_hit_records(ctx->stream, rp, sc, ctx->ps, *ctx->h_count, ctx->d_hits);
     CHK(hipMemcpyAsync(out, ctx->d_hits, (size_t)width * height * sizeof(PtcHitRecord), hipMemcpyDeviceToHost, ctx->stream));
     CHK(hipStreamSynchronize(ctx->stream));
     CHK(hipGetLastError());

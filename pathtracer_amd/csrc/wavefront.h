@@ -10,29 +10,29 @@
 #include "device_scene.h"
 
 void wf_generate(hipStream_t s, const RenderParams& rp, const PathState& ps, uint32_t npix_pad, uint32_t n_paths, uint32_t sample_begin,
-                 const float* acc, uint32_t* segctr, int seed_L_from_acc, uint32_t* queue, uint32_t* qcount);
-// closest hits of queue[0..count) into the path slots; `work_counter` is a zeroed device word
-// the refilling waves reserve their spans from; `coherent` = camera rays
-void wf_extend(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, uint32_t count, uint32_t* work_counter,
+                 const float* acc, uint32_t* segctr, int seed_L_from_acc, uint32_t* qcount);
+// closest hits of the live paths (entries [0, count) of the packed path state); `work_counter`
+// is a zeroed device word the refilling waves reserve their spans from; `coherent` = camera rays
+void wf_extend(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, uint32_t count, uint32_t* work_counter,
                uint32_t resident_waves, bool coherent, bool count_trav, unsigned long long* trav_counters);
 uint32_t wf_resident_waves(int device);
-// compacted queue of the paths that hit something (misses end there)
-void wf_compact_hits(hipStream_t s, const RenderParams& rp, const PathState& ps, const uint32_t* queue, uint32_t count, uint32_t* hit_queue, uint32_t* hit_count);
+// positions of the paths that hit something (misses end there)
+void wf_compact_hits(hipStream_t s, const RenderParams& rp, const PathState& ps, uint32_t count, uint32_t* hit_queue, uint32_t* hit_count);
 // Everything of a bounce's closest-hit programs that does not depend on shadow-ray
 // visibility: light samples (terms + shadow rays, their count in `shadow_count`), emission,
-// next direction / throughput, survivors -> next_queue; segments whose radiance needs the
+// next direction / throughput, survivors -> the `*_next` path state, packed; segments whose radiance needs the
 // light terms -> gather_queue.
 // surface / shadow / gather read their queue length from device memory; `max_*` sizes the grid
 void wf_surface(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, const uint32_t* count_ptr,
-                uint32_t max_count, uint32_t npix_pad, uint32_t sample_begin, uint32_t* segctr, uint32_t* next_queue, uint32_t* next_count,
+                uint32_t max_count, uint32_t npix_pad, uint32_t sample_begin, uint32_t* segctr, uint32_t* next_count,
                 uint32_t* gather_queue, uint32_t* gather_count, uint32_t* shadow_count);
 void wf_shadow(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* count_ptr, uint64_t max_rays,
                uint32_t* work_counter, uint32_t resident_waves, bool count_trav, unsigned long long* trav_counters, unsigned long long* shadow_total);
-void wf_gather(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* hit_queue, const uint32_t* gather_queue,
-               const uint32_t* gather_count, uint32_t max_count);
+void wf_gather(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* gather_queue, const uint32_t* gather_count,
+               uint32_t max_count);
 void wf_accumulate(hipStream_t s, const RenderParams& rp, const PathState& ps, uint32_t npix_pad, uint32_t n_samples, float* acc, int replace);
 void wf_resolve(hipStream_t s, const float* acc, float* result, uint32_t n_pixels, int spp, float gamma, int frame_id);
-void wf_hit_records(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, uint32_t npix_pad, PtcHitRecord* out);
+void wf_hit_records(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, uint32_t count, PtcHitRecord* out);
 
 // ---- BVH build (bvh_build.hip) ----------------------------------------------
 struct BvhBuildInput {

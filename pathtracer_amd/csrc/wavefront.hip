@@ -206,7 +206,7 @@ __device__ __forceinline__ uint32_t segment_seed(const RenderParams& rp, uint32_
 
 __global__ __launch_bounds__(GEN_BLOCK) void k_generate(RenderParams rp, PathState ps, uint32_t npix_pad, uint32_t n_paths, uint32_t sample_begin,
                                                     const float* __restrict__ acc, uint32_t* __restrict__ segctr, int seed_L_from_acc,
-                                                    uint32_t* __restrict__ queue, uint32_t* __restrict__ qcount) {
+                                                    uint32_t* __restrict__ qcount) {
     const uint32_t p = blockIdx.x * GEN_BLOCK + threadIdx.x;
     bool valid = p < n_paths;
     uint32_t x = 0, y = 0, pix = 0, j = 0;
@@ -214,6 +214,8 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_generate(RenderParams rp, PathSta
         j = sample_begin + div_by(p, npix_pad, rp.inv_npix_pad, pix);
         valid = pixel_of(rp, pix, x, y);
     }
+    // live paths are kept packed: this one's state goes to position `at`
+    const uint32_t at = queue_reserve(valid, qcount);
     if (valid) {
         const PtcConfig& cf = rp.cf;
         const uint32_t index = x * rp.height + y;  // PinholeCamera.cu:23
@@ -229,9 +231,10 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_generate(RenderParams rp, PathSta
         const float aby = cf.tanHFov.y * (py - cf.hSize.y) / cf.hSize.y;
         const vec3 dir = normalize(abx * P3v(cf.u) + aby * P3v(cf.v) - P3v(cf.w));  // :51
         const uint32_t seed = segment_seed(rp, key0, j, 0u, segctr, pix);
-        ps.o_seed[p] = make_float4(cf.eye.x, cf.eye.y, cf.eye.z, u2f(seed));
-        ps.d_depth[p] = make_float4(dir.x, dir.y, dir.z, u2f(0u));
-        ps.thr[p] = make_float4(1.f, 1.f, 1.f, u2f(0u));
+        ps.o_seed[at] = make_float4(cf.eye.x, cf.eye.y, cf.eye.z, u2f(seed));
+        ps.d_depth[at] = make_float4(dir.x, dir.y, dir.z, u2f(0u));
+        ps.thr[at] = make_float4(1.f, 1.f, 1.f, u2f(0u));
+        ps.pid[at] = p;
         float4 L = make_float4(0.f, 0.f, 0.f, 0.f);
         if (seed_L_from_acc) {
             const float* a = acc + 3 * ((size_t)y * rp.width + x);
@@ -239,7 +242,6 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_generate(RenderParams rp, PathSta
         }
         ps.L[p] = L;
     }
-    queue_append(valid, p, queue, qcount);
 }
 
 // ------------------------------------------------------------------ extend --
@@ -275,9 +277,10 @@ __device__ __forceinline__ uint32_t wave_fetch(WaveWork& w, bool idle, uint32_t*
     return idx;
 }
 
-// Closest hit of every queued path: hit_t / hit_ref of the path's slot.
+// Closest hit of the live paths, i.e. of entries [0, count) of the path state: hit_t / hit_ref
+// at the same position.
 template <bool COUNT>
-__global__ __launch_bounds__(BLOCK) void k_extend(RenderParams rp, DevScene sc, PathState ps, const uint32_t* __restrict__ queue, uint32_t count,
+__global__ __launch_bounds__(BLOCK) void k_extend(RenderParams rp, DevScene sc, PathState ps, uint32_t count,
                                                   uint32_t* __restrict__ work_counter, uint32_t wave_chunk, unsigned long long* __restrict__ trav_counters) {
     __shared__ uint32_t stack[TRAV_LDS_STACK * BLOCK];
     uint32_t* my_stack = stack + threadIdx.x;
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend(RenderParams rp, DevScene sc, 
         if (nidle >= rp.tune_refill && !(w.drained && w.pos >= w.end)) {
             const uint32_t idx = wave_fetch(w, !active, work_counter, wave_chunk, count);
             if (idx != 0xFFFFFFFFu) {
-                p = queue[idx];
+                p = idx;
                 const float4 o4 = ps.o_seed[p], d4 = ps.d_depth[p];
                 active = trav_init(sc, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), rp.cf.epsilon, PT_RAY_MAX, r, sp, cur, best);
                 if (!active) {  // NaN direction or empty scene: a miss
@@ -328,12 +331,12 @@ __global__ __launch_bounds__(BLOCK) void k_extend(RenderParams rp, DevScene sc, 
 // refilling variant above: the per-round bookkeeping of the latter costs more issue
 // slots than the idle lanes it recovers.
 template <bool COUNT>
-__global__ __launch_bounds__(BLOCK) void k_extend_static(RenderParams rp, DevScene sc, PathState ps, const uint32_t* __restrict__ queue, uint32_t count,
+__global__ __launch_bounds__(BLOCK) void k_extend_static(RenderParams rp, DevScene sc, PathState ps, uint32_t count,
                                                          unsigned long long* __restrict__ trav_counters) {
     __shared__ uint32_t stack[TRAV_LDS_STACK * BLOCK];
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= count) return;
-    const uint32_t p = queue[i];
+    const uint32_t p = i;
     const float4 o4 = ps.o_seed[p], d4 = ps.d_depth[p];
     ClosestHit best;
     TravCounters cnt = {0u, 0u};
@@ -444,7 +447,7 @@ __device__ __forceinline__ void deferred_item(const DevScene& sc, DeferredLds& L
 #define DQ_MIN_WAVES 6   /* waves per SIMD the register allocation aims at (LDS allows 6 blocks per CU) */
 #endif
 template <bool ANY, bool COUNT>
-__global__ __launch_bounds__(BLOCK, DQ_MIN_WAVES) void k_trace_deferred(RenderParams rp, DevScene sc, PathState ps, const uint32_t* __restrict__ queue,
+__global__ __launch_bounds__(BLOCK, DQ_MIN_WAVES) void k_trace_deferred(RenderParams rp, DevScene sc, PathState ps,
                                                           const uint32_t* __restrict__ count_ptr, uint32_t count_arg,
                                                           uint32_t* __restrict__ work_counter, uint32_t wave_chunk,
                                                           unsigned long long* __restrict__ trav_counters, unsigned long long* __restrict__ shadow_total) {
@@ -504,7 +507,7 @@ __global__ __launch_bounds__(BLOCK, DQ_MIN_WAVES) void k_trace_deferred(RenderPa
                         p = f2u(d4.w);   // slot of the ray's term
                         d4.w = o4.w;     // tmax
                     } else {
-                        p = queue[idx];
+                        p = idx;
                         o4 = ps.o_seed[p];
                         d4 = ps.d_depth[p];
                         d4.w = PT_RAY_MAX;
@@ -581,10 +584,10 @@ __global__ __launch_bounds__(BLOCK, DQ_MIN_WAVES) void k_trace_deferred(RenderPa
 }
 
 // Brute force over all primitives (parity aid).
-__global__ __launch_bounds__(BLOCK) void k_extend_brute(RenderParams rp, DevScene sc, PathState ps, const uint32_t* __restrict__ queue, uint32_t count) {
+__global__ __launch_bounds__(BLOCK) void k_extend_brute(RenderParams rp, DevScene sc, PathState ps, uint32_t count) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= count) return;
-    const uint32_t p = queue[i];
+    const uint32_t p = i;
     const float4 o4 = ps.o_seed[p], d4 = ps.d_depth[p];
     ClosestHit best;
     brute_force<false>(sc, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), rp.cf.epsilon, PT_RAY_MAX, best);
@@ -592,11 +595,11 @@ __global__ __launch_bounds__(BLOCK) void k_extend_brute(RenderParams rp, DevScen
     ps.hit_ref[p] = best.ref;
 }
 
-// Paths that hit something go to `hit_queue` (the only ones the surface kernel looks at,
-// so that its waves are full); a miss ends the path right here: radiance = background
+// The positions of the paths that hit something go to `hit_queue` (the only ones the
+// surface kernel looks at, so that its waves are full); a miss ends the path right here: radiance = background
 // colour, not scaled by the throughput (Common.cu:13-18).
-__global__ __launch_bounds__(GEN_BLOCK) void k_compact_hits(RenderParams rp, PathState ps, const uint32_t* __restrict__ queue, uint32_t count,
-                                                        uint32_t* __restrict__ hit_queue, uint32_t* __restrict__ hit_count) {
+__global__ __launch_bounds__(GEN_BLOCK) void k_compact_hits(RenderParams rp, PathState ps, uint32_t count, uint32_t* __restrict__ hit_queue,
+                                                        uint32_t* __restrict__ hit_count) {
     bool hit[GEN_CHUNKS];
     uint32_t ps_[GEN_CHUNKS], at[GEN_CHUNKS];
     const bool bg = rp.bg[0] != 0.f || rp.bg[1] != 0.f || rp.bg[2] != 0.f;
@@ -606,10 +609,10 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_compact_hits(RenderParams rp, Pat
         hit[c] = false;
         ps_[c] = 0;
         if (i < count) {
-            const uint32_t p = queue[i];
-            ps_[c] = p;
-            hit[c] = ps.hit_ref[p] != HIT_MISS;
+            ps_[c] = i;
+            hit[c] = ps.hit_ref[i] != HIT_MISS;
             if (!hit[c] && bg) {
+                const uint32_t p = ps.pid[i];
                 float4 L = ps.L[p];
                 L.x += rp.bg[0];
                 L.y += rp.bg[1];
@@ -1174,7 +1177,7 @@ __device__ __forceinline__ vec3 gather_radiance(const RenderParams& rp, const De
 template <int INTEG>
 __global__ __launch_bounds__(SURF_BLOCK) void k_surface(RenderParams rp, DevScene sc, PathState ps, const uint32_t* __restrict__ queue,
                                                        const uint32_t* __restrict__ count_ptr, uint32_t npix_pad, uint32_t sample_begin, uint32_t* __restrict__ segctr,
-                                                       uint32_t* __restrict__ next_queue, uint32_t* __restrict__ next_count,
+                                                       uint32_t* __restrict__ next_count,
                                                        uint32_t* __restrict__ gather_queue, uint32_t* __restrict__ gather_count,
                                                        uint32_t* __restrict__ shadow_count) {
     const uint32_t count = *count_ptr;  // hits of this bounce, written by k_compact_hits
@@ -1185,9 +1188,12 @@ __global__ __launch_bounds__(SURF_BLOCK) void k_surface(RenderParams rp, DevScen
     uint32_t p = 0, bounce = 0;
     Segment sg;
     HitAttr at;
+    uint32_t at_state = 0;  // position of the path's state
+    float4 n_o = make_float4(0.f, 0.f, 0.f, 0.f), n_d = n_o, n_t = n_o;  // state of the next segment
     if (hit) {
-        p = queue[i];
-        const float4 o4 = ps.o_seed[p], d4 = ps.d_depth[p], t4 = ps.thr[p];
+        at_state = queue[i];
+        p = ps.pid[at_state];
+        const float4 o4 = ps.o_seed[at_state], d4 = ps.d_depth[at_state], t4 = ps.thr[at_state];
         sg.o = mk3(o4.x, o4.y, o4.z);
         sg.d = mk3(d4.x, d4.y, d4.z);
         sg.thr = mk3(t4.x, t4.y, t4.z);
@@ -1195,7 +1201,7 @@ __global__ __launch_bounds__(SURF_BLOCK) void k_surface(RenderParams rp, DevScen
         sg.depth = f2u(d4.w);
         sg.done = false;
         bounce = f2u(t4.w);
-        hit_attributes(sc, ps.hit_ref[p], ps.hit_t[p], sg.o, sg.d, at);
+        hit_attributes(sc, ps.hit_ref[at_state], ps.hit_t[at_state], sg.o, sg.d, at);
         sample = rp.samples_per_path != 0u && samples_lights<INTEG>(rp, at.mat, sg.depth);
     }
     // ---- the light samples: term + shadow ray each; a term that is exactly zero adds
@@ -1260,7 +1266,7 @@ __global__ __launch_bounds__(SURF_BLOCK) void k_surface(RenderParams rp, DevScen
         if (gather) {
             // w: does the first-hit rule of pathTracer include the emission (:900-903)
             ps.g_a[i] = make_float4(out.a.x, out.a.y, out.a.z, u2f((!rp.cf.next_event_est || depth_before == 0u) ? 1u : 0u));
-            ps.g_thr[i] = make_float4(thr_before.x, thr_before.y, thr_before.z, 0.f);
+            ps.g_thr[i] = make_float4(thr_before.x, thr_before.y, thr_before.z, u2f(p));
         } else {
             // gather wanted but there is not a single light sample (lightsamples 0): the same
             // formulas over zero terms, here
@@ -1282,11 +1288,12 @@ __global__ __launch_bounds__(SURF_BLOCK) void k_surface(RenderParams rp, DevScen
             pixel_of(rp, pix, x, y);
             const uint32_t key0 = (x * rp.height + y) * rp.frame_id;
             const uint32_t seed = segment_seed(rp, key0, sample, bounce, segctr, pix);
-            ps.o_seed[p] = make_float4(sg.o.x, sg.o.y, sg.o.z, u2f(seed));
-            ps.d_depth[p] = make_float4(sg.d.x, sg.d.y, sg.d.z, u2f(sg.depth));
-            ps.thr[p] = make_float4(sg.thr.x, sg.thr.y, sg.thr.z, u2f(bounce));
+            n_o = make_float4(sg.o.x, sg.o.y, sg.o.z, u2f(seed));
+            n_d = make_float4(sg.d.x, sg.d.y, sg.d.z, u2f(sg.depth));
+            n_t = make_float4(sg.thr.x, sg.thr.y, sg.thr.z, u2f(bounce));
         }
     }
+    uint32_t next_at = 0;  // the survivor's position in the next bounce's (packed) path state
     if (few) {
         uint32_t pos[4];
         queue_reserve4(f_need[0], f_need[1], gather, alive, shadow_count, gather_count, next_count, pos);
@@ -1297,22 +1304,28 @@ __global__ __launch_bounds__(SURF_BLOCK) void k_surface(RenderParams rp, DevScen
                 ps.sh_d[pos[q]] = make_float4(f_d[q].x, f_d[q].y, f_d[q].z, u2f(f_slot[q]));
             }
         if (gather) gather_queue[pos[2]] = i;
-        if (alive) next_queue[pos[3]] = p;
+        next_at = pos[3];
     } else {
         queue_append(gather, i, gather_queue, gather_count);
-        queue_append(alive, p, next_queue, next_count);
+        next_at = queue_reserve(alive, next_count);
+    }
+    if (alive) {
+        ps.o_seed_next[next_at] = n_o;
+        ps.d_depth_next[next_at] = n_d;
+        ps.thr_next[next_at] = n_t;
+        ps.pid_next[next_at] = p;
     }
 }
 
 // After k_shadow: the radiance of the segments that sampled the lights.
 template <int INTEG>
-__global__ __launch_bounds__(GEN_BLOCK) void k_gather(RenderParams rp, DevScene sc, PathState ps, const uint32_t* __restrict__ hit_queue,
-                                                      const uint32_t* __restrict__ gather_queue, const uint32_t* __restrict__ gather_count) {
+__global__ __launch_bounds__(GEN_BLOCK) void k_gather(RenderParams rp, DevScene sc, PathState ps, const uint32_t* __restrict__ gather_queue,
+                                                      const uint32_t* __restrict__ gather_count) {
     const uint32_t i = blockIdx.x * GEN_BLOCK + threadIdx.x;
     if (i >= *gather_count) return;
     const uint32_t seg = gather_queue[i];  // position in the hit queue
-    const uint32_t p = hit_queue[seg];
     const float4 a4 = ps.g_a[seg], t4 = ps.g_thr[seg];
+    const uint32_t p = f2u(t4.w);
     const vec3 a = mk3(a4.x, a4.y, a4.z), thr = mk3(t4.x, t4.y, t4.z);
     const vec3 radiance = gather_radiance<INTEG>(rp, sc, ps, seg, a, thr, f2u(a4.w) != 0u);
     float4 L = ps.L[p];
@@ -1360,19 +1373,19 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(const float* __restrict__ acc
 }
 
 // -------------------------------------------------------------- hit records --
-__global__ __launch_bounds__(BLOCK) void k_hit_records(RenderParams rp, DevScene sc, PathState ps, uint32_t npix_pad, PtcHitRecord* __restrict__ out) {
-    const uint32_t pix = blockIdx.x * BLOCK + threadIdx.x;
-    if (pix >= npix_pad) return;
+__global__ __launch_bounds__(BLOCK) void k_hit_records(RenderParams rp, DevScene sc, PathState ps, uint32_t count, PtcHitRecord* __restrict__ out) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;  // position of a camera path of sample 0
+    if (i >= count) return;
     uint32_t x, y;
-    if (!pixel_of(rp, pix, x, y)) return;
+    if (!pixel_of(rp, ps.pid[i], x, y)) return;
     PtcHitRecord rec;
     rec.prim = -1;
     rec.t = rec.u = rec.v = 0.f;
-    const int ref = ps.hit_ref[pix];
+    const int ref = ps.hit_ref[i];
     if (ref != HIT_MISS) {
-        rec.t = ps.hit_t[pix];
+        rec.t = ps.hit_t[i];
         if (ref >= 0) {
-            const float4 o4 = ps.o_seed[pix], d4 = ps.d_depth[pix];
+            const float4 o4 = ps.o_seed[i], d4 = ps.d_depth[i];
             const float4* q = sc.tri_q + 3 * (size_t)ref;
             const Cand c = tri_candidate(q[0], q[1], q[2], mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), 0.f, PT_RAY_MAX);
             rec.u = c.u;
@@ -1389,9 +1402,9 @@ __global__ __launch_bounds__(BLOCK) void k_hit_records(RenderParams rp, DevScene
 static inline uint32_t blocks_for(uint64_t n, uint32_t block = BLOCK) { return (uint32_t)((n + block - 1) / block); }
 
 void wf_generate(hipStream_t s, const RenderParams& rp, const PathState& ps, uint32_t npix_pad, uint32_t n_paths, uint32_t sample_begin,
-                 const float* acc, uint32_t* segctr, int seed_L_from_acc, uint32_t* queue, uint32_t* qcount) {
+                 const float* acc, uint32_t* segctr, int seed_L_from_acc, uint32_t* qcount) {
     hipLaunchKernelGGL(k_generate, dim3(blocks_for(n_paths, GEN_BLOCK)), dim3(GEN_BLOCK), 0, s, rp, ps, npix_pad, n_paths, sample_begin, acc, segctr,
-                       seed_L_from_acc, queue, qcount);
+                       seed_L_from_acc, qcount);
 }
 
 // Grid and per-wave span of a traversal launch over (at most) n rays: enough waves to
@@ -1425,7 +1438,7 @@ static uint32_t deferred_resident_waves() {
 // The item word of the deferred-test kernels holds 25 bits of primitive slot.
 static bool deferred_fits(const DevScene& sc) { return sc.n_tris < (1u << 25) && sc.n_spheres < (1u << 25); }
 
-void wf_extend(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, uint32_t count, uint32_t* work_counter, uint32_t resident_waves, bool coherent, bool count_trav,
+void wf_extend(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, uint32_t count, uint32_t* work_counter, uint32_t resident_waves, bool coherent, bool count_trav,
                unsigned long long* trav_counters) {
     if (count == 0) return;
     uint32_t blocks, wave_chunk;
@@ -1438,19 +1451,19 @@ void wf_extend(hipStream_t s, const RenderParams& rp, const DevScene& sc, const 
     // thread is fastest; scattered rays finish at very different times, refilling pays
     // (mode 5: the same with deferred primitive tests for the scattered rays)
     if (rp.brute_force)
-        hipLaunchKernelGGL(k_extend_brute, dim3(blocks_for(count)), dim3(BLOCK), 0, s, rp, sc, ps, queue, count);
+        hipLaunchKernelGGL(k_extend_brute, dim3(blocks_for(count)), dim3(BLOCK), 0, s, rp, sc, ps, count);
     else if (mode == 4 && count_trav)
-        hipLaunchKernelGGL((k_trace_deferred<false, true>), dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, queue, nullptr, count, work_counter, wave_chunk, trav_counters, nullptr);
+        hipLaunchKernelGGL((k_trace_deferred<false, true>), dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, nullptr, count, work_counter, wave_chunk, trav_counters, nullptr);
     else if (mode == 4)
-        hipLaunchKernelGGL((k_trace_deferred<false, false>), dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, queue, nullptr, count, work_counter, wave_chunk, trav_counters, nullptr);
+        hipLaunchKernelGGL((k_trace_deferred<false, false>), dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, nullptr, count, work_counter, wave_chunk, trav_counters, nullptr);
     else if (mode == 0 && count_trav)
-        hipLaunchKernelGGL(k_extend_static<true>, dim3(blocks_for(count)), dim3(BLOCK), 0, s, rp, sc, ps, queue, count, trav_counters);
+        hipLaunchKernelGGL(k_extend_static<true>, dim3(blocks_for(count)), dim3(BLOCK), 0, s, rp, sc, ps, count, trav_counters);
     else if (mode == 0)
-        hipLaunchKernelGGL(k_extend_static<false>, dim3(blocks_for(count)), dim3(BLOCK), 0, s, rp, sc, ps, queue, count, trav_counters);
+        hipLaunchKernelGGL(k_extend_static<false>, dim3(blocks_for(count)), dim3(BLOCK), 0, s, rp, sc, ps, count, trav_counters);
     else if (count_trav)
-        hipLaunchKernelGGL(k_extend<true>, dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, queue, count, work_counter, wave_chunk, trav_counters);
+        hipLaunchKernelGGL(k_extend<true>, dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, count, work_counter, wave_chunk, trav_counters);
     else
-        hipLaunchKernelGGL(k_extend<false>, dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, queue, count, work_counter, wave_chunk, trav_counters);
+        hipLaunchKernelGGL(k_extend<false>, dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, count, work_counter, wave_chunk, trav_counters);
 }
 
 // Traces the shadow rays k_surface queued (their number is in device memory, at most `max_rays`).
@@ -1464,9 +1477,9 @@ void wf_shadow(hipStream_t s, const RenderParams& rp, const DevScene& sc, const 
     if (rp.brute_force)
         hipLaunchKernelGGL(k_shadow_brute, dim3(blocks_for(max_rays)), dim3(BLOCK), 0, s, rp, sc, ps, count_ptr, shadow_total);
     else if (smode == 4 && count_trav)
-        hipLaunchKernelGGL((k_trace_deferred<true, true>), dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, nullptr, count_ptr, 0u, work_counter, wave_chunk, trav_counters, shadow_total);
+        hipLaunchKernelGGL((k_trace_deferred<true, true>), dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, count_ptr, 0u, work_counter, wave_chunk, trav_counters, shadow_total);
     else if (smode == 4)
-        hipLaunchKernelGGL((k_trace_deferred<true, false>), dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, nullptr, count_ptr, 0u, work_counter, wave_chunk, trav_counters, shadow_total);
+        hipLaunchKernelGGL((k_trace_deferred<true, false>), dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, count_ptr, 0u, work_counter, wave_chunk, trav_counters, shadow_total);
     else if (smode == 0 && count_trav)
         hipLaunchKernelGGL(k_shadow_static<true>, dim3(blocks_for(max_rays)), dim3(BLOCK), 0, s, rp, sc, ps, count_ptr, trav_counters, shadow_total);
     else if (smode == 0)
@@ -1486,18 +1499,18 @@ uint32_t wf_resident_waves(int device) {
 }
 
 // Queue of the paths whose extension ray hit something; misses end there.
-void wf_compact_hits(hipStream_t s, const RenderParams& rp, const PathState& ps, const uint32_t* queue, uint32_t count, uint32_t* hit_queue, uint32_t* hit_count) {
+void wf_compact_hits(hipStream_t s, const RenderParams& rp, const PathState& ps, uint32_t count, uint32_t* hit_queue, uint32_t* hit_count) {
     if (count == 0) return;
-    hipLaunchKernelGGL(k_compact_hits, dim3(blocks_for(count, GEN_BLOCK * GEN_CHUNKS)), dim3(GEN_BLOCK), 0, s, rp, ps, queue, count, hit_queue, hit_count);
+    hipLaunchKernelGGL(k_compact_hits, dim3(blocks_for(count, GEN_BLOCK * GEN_CHUNKS)), dim3(GEN_BLOCK), 0, s, rp, ps, count, hit_queue, hit_count);
 }
 
 // `count_ptr` (device) holds the number of queued paths; `max_count` bounds it and sizes the grid.
 void wf_surface(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, const uint32_t* count_ptr,
-                uint32_t max_count, uint32_t npix_pad, uint32_t sample_begin, uint32_t* segctr, uint32_t* next_queue, uint32_t* next_count,
+                uint32_t max_count, uint32_t npix_pad, uint32_t sample_begin, uint32_t* segctr, uint32_t* next_count,
                 uint32_t* gather_queue, uint32_t* gather_count, uint32_t* shadow_count) {
     if (max_count == 0) return;
     const dim3 g(blocks_for(max_count, SURF_BLOCK)), b(SURF_BLOCK);
-#define PT_SURFACE(I) hipLaunchKernelGGL(k_surface<I>, g, b, 0, s, rp, sc, ps, queue, count_ptr, npix_pad, sample_begin, segctr, next_queue, next_count, gather_queue, gather_count, shadow_count)
+#define PT_SURFACE(I) hipLaunchKernelGGL(k_surface<I>, g, b, 0, s, rp, sc, ps, queue, count_ptr, npix_pad, sample_begin, segctr, next_count, gather_queue, gather_count, shadow_count)
     switch (rp.integrator) {
         case INT_RAYTRACER: PT_SURFACE(INT_RAYTRACER); break;
         case INT_ANALYTICDIRECT: PT_SURFACE(INT_ANALYTICDIRECT); break;
@@ -1510,15 +1523,15 @@ void wf_surface(hipStream_t s, const RenderParams& rp, const DevScene& sc, const
 }
 
 // `gather_count` (device) holds the number of queued paths; `max_count` bounds it and sizes the grid.
-void wf_gather(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* hit_queue, const uint32_t* gather_queue,
-               const uint32_t* gather_count, uint32_t max_count) {
+void wf_gather(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* gather_queue, const uint32_t* gather_count,
+               uint32_t max_count) {
     if (max_count == 0) return;
     const dim3 g(blocks_for(max_count, GEN_BLOCK)), b(GEN_BLOCK);
     switch (rp.integrator) {
-        case INT_RAYTRACER: hipLaunchKernelGGL(k_gather<INT_RAYTRACER>, g, b, 0, s, rp, sc, ps, hit_queue, gather_queue, gather_count); break;
-        case INT_DIRECT: hipLaunchKernelGGL(k_gather<INT_DIRECT>, g, b, 0, s, rp, sc, ps, hit_queue, gather_queue, gather_count); break;
-        case INT_PATHTRACER: hipLaunchKernelGGL(k_gather<INT_PATHTRACER>, g, b, 0, s, rp, sc, ps, hit_queue, gather_queue, gather_count); break;
-        case INT_PATHTRACER2: hipLaunchKernelGGL(k_gather<INT_PATHTRACER2>, g, b, 0, s, rp, sc, ps, hit_queue, gather_queue, gather_count); break;
+        case INT_RAYTRACER: hipLaunchKernelGGL(k_gather<INT_RAYTRACER>, g, b, 0, s, rp, sc, ps, gather_queue, gather_count); break;
+        case INT_DIRECT: hipLaunchKernelGGL(k_gather<INT_DIRECT>, g, b, 0, s, rp, sc, ps, gather_queue, gather_count); break;
+        case INT_PATHTRACER: hipLaunchKernelGGL(k_gather<INT_PATHTRACER>, g, b, 0, s, rp, sc, ps, gather_queue, gather_count); break;
+        case INT_PATHTRACER2: hipLaunchKernelGGL(k_gather<INT_PATHTRACER2>, g, b, 0, s, rp, sc, ps, gather_queue, gather_count); break;
         default: break;
     }
 }
@@ -1531,6 +1544,7 @@ void wf_resolve(hipStream_t s, const float* acc, float* result, uint32_t n_pixel
     hipLaunchKernelGGL(k_resolve, dim3(blocks_for(n_pixels)), dim3(BLOCK), 0, s, acc, result, n_pixels, spp, gamma, frame_id);
 }
 
-void wf_hit_records(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, uint32_t npix_pad, PtcHitRecord* out) {
-    hipLaunchKernelGGL(k_hit_records, dim3(blocks_for(npix_pad)), dim3(BLOCK), 0, s, rp, sc, ps, npix_pad, out);
+void wf_hit_records(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, uint32_t count, PtcHitRecord* out) {
+    if (count == 0) return;
+    hipLaunchKernelGGL(k_hit_records, dim3(blocks_for(count)), dim3(BLOCK), 0, s, rp, sc, ps, count, out);
 }
