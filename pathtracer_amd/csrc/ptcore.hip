@@ -10,8 +10,6 @@
 
 #include <algorithm>
 #include <cmath>
-#include <cstdio>
-#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -350,14 +348,6 @@ int runBounces(ptc_context* ctx, const RenderParams& rp, const DevScene& sc, uin
         CHK(hipMemcpyAsync(ctx->h_count, grp + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         CHK(hipStreamSynchronize(ctx->stream));
         CHK(hipGetLastError());
-        if (ctx->count_trav && getenv("PTC_DEBUG_BOUNCES")) {
-            unsigned long long h[8];
-            uint32_t q[8];
-            (void)hipMemcpy(h, ctx->counters, sizeof(h), hipMemcpyDeviceToHost);
-            (void)hipMemcpy(q, grp, sizeof(q), hipMemcpyDeviceToHost);
-            fprintf(stderr, "[ptc] bounce %u: rays %u hits %u shadow %u next %u | cumulative ext nodes %llu prims %llu shadow nodes %llu prims %llu\n", bounce,
-                    count, q[0], q[2], q[1], h[0], h[1], h[2], h[3]);
-        }
         count = *ctx->h_count;
         // the survivors' packed state becomes the current one
         std::swap(ctx->ps.o_seed, ctx->ps.o_seed_next);
@@ -776,7 +766,6 @@ int ptc_get_stats(ptc_context* ctx, PtcStats* out) {
     ctx->stats.shadow_nodes_visited = h[2];
     ctx->stats.shadow_prims_tested = h[3];
     ctx->stats.shadow_rays = h[4];
-    if (getenv("PTC_DEBUG_MAX")) fprintf(stderr, "[ptc] max nodes/ray %llu max prims/ray %llu\n", h[5], h[6]);
     *out = ctx->stats;
     return PTC_OK;
 }
