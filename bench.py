@@ -24,6 +24,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {
+    # BASELINE.json configs[0]: spheres + quad lights, `direct`, 640x480, 16 spp (scene 2/sphere.test: the
+    # shipped scene with quad lights and the direct integrator; 75 stratified shadow rays per path)
+    "sphere": dict(scene="scene2/sphere.test", over=dict(size="640 480", spp="16"),
+                   name="scene 2 sphere.test (1 sphere, 2 triangles, 3 quad lights, 25 stratified samples each) direct lighting, 640x480, 16 spp"),
     # BASELINE.json configs[3]: Stanford dragon GGX, 1080p, 256 spp (BVH-traversal bound)
     "dragon": dict(scene="scene4/dragon.test", over=dict(size="1920 1080", spp="256"),
                    name="Stanford dragon (100006 tris, 2 quad lights) GGX BRDF sampling + NEE + RR, maxdepth 5, 1920x1080, 256 spp"),
@@ -164,7 +168,7 @@ def main():
             if t.get("workload") == args.workload and "extend" in t:
                 traffic = round(t["extend"]["fetch_bytes_per_launch"] + t["extend"]["write_bytes_per_launch"], 1)
         roofline = {
-            "bound": "hbm", "kernel": "k_extend_static + k_trace_deferred<false> (extension-ray traversal)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "bound": "hbm", "kernel": "extension-ray traversal (k_extend_static for camera rays and tiny hierarchies, k_trace_deferred<false> otherwise)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "algorithmic_bytes_per_launch": round(b_ext * st.extension_rays / launches, 1),
             "bytes_per_ray": round(b_ext, 1), "nodes_per_ray": round(nodes_per_ray, 2), "prims_per_ray": round(prims_per_ray, 2),
