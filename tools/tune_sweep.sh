@@ -1,7 +1,12 @@
 #!/bin/bash
-# usage: tools/tune_sweep.sh "<bench args>" tune1 tune2 ...   (prints Mrays/s and kernel ms per tune value)
-args=$1; shift
-for t in "$@"; do
-  out=$(timeout -k 10 200 python bench.py $args --no-cpu-baseline --tune $t 2>/dev/null | tail -1)
-  echo "tune=$t $(echo "$out" | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"], d["roofline"]["kernel_ms"])')"
+# A/B sweep of bench.py; each argument is  <tune>[@<variant>]  where <tune> is a
+# PTC_OPT_TUNE_TRAVERSAL value and <variant> a library built by tools/build_variant.sh.
+# One bench line per argument in gpurun_out/tune_sweep.txt.  WORKLOAD=dragon|cornell|... (default dragon).
+out=gpurun_out/tune_sweep.txt
+: > $out
+for a in "$@"; do
+  t=${a%@*}; v=""; [[ "$a" == *@* ]] && v=${a#*@}
+  echo "tune $a" >> $out
+  if [ -n "$v" ]; then export PTCORE_LIB=$PWD/pathtracer_amd/_lib/variants/libptcore_$v.so; else unset PTCORE_LIB; fi
+  timeout -k 10 200 python bench.py --workload ${WORKLOAD:-dragon} --steps 2 --warmup 1 --no-cpu-baseline --tune $t 2>/dev/null >> $out || exit 1
 done
