@@ -189,3 +189,51 @@ def test_command_line_writes_the_same_png(tmp_path):
     # errors are printed, the exit status stays 0 (main.cpp:47-52)
     bad = subprocess.run([exe, str(tmp_path / "missing.test")], capture_output=True, text=True, timeout=60)
     assert bad.returncode == 0 and bad.stderr.strip()
+
+
+def soup(n_tris, n_spheres, seed, degenerate=False):
+    """Random triangle soup (+ ellipsoids) around the origin with the camera inside it."""
+    rng = np.random.default_rng(seed)
+    lines = ["size 80 60", "integrator raytracer", "maxdepth 2", "camera 0.1 0.05 0.2 0 0 -1 0 1 0 70", "point 0 0 0 1 1 1", "diffuse 0.5 0.5 0.5",
+             f"maxverts {3 * n_tris}"]
+    verts, tris = [], []
+    for i in range(n_tris):
+        c = rng.uniform(-2, 2, 3)
+        if degenerate and i % 3 == 0:
+            c = np.array([0.5, 0.5, -1.0])          # many primitives with the same centroid
+        size = 0.06 if not degenerate or i % 5 else 3.0  # a few huge ones among tiny ones
+        for _ in range(3):
+            v = c + rng.uniform(-size, size, 3)
+            verts.append(f"vertex {v[0]:.5f} {v[1]:.5f} {v[2]:.5f}")
+        if degenerate and i % 7 == 0:
+            verts[-1] = verts[-2]                      # zero-area triangle
+        tris.append(f"tri {3 * i} {3 * i + 1} {3 * i + 2}")
+    lines += verts + tris
+    for _ in range(n_spheres):
+        x, y, z = rng.uniform(-2, 2, 3)
+        lines += ["pushTransform", f"translate {x:.4f} {y:.4f} {z:.4f}", f"scale {rng.uniform(0.2, 2):.3f} 1 {rng.uniform(0.2, 2):.3f}",
+                  f"sphere 0 0 0 {rng.uniform(0.02, 0.2):.3f}", "popTransform"]
+    return SceneLoader().loadText("\n".join(lines) + "\n")
+
+
+@pytest.mark.parametrize("builder", [0, 1])
+@pytest.mark.parametrize("case", [dict(n_tris=6000, n_spheres=60, seed=11), dict(n_tris=3000, n_spheres=0, seed=12, degenerate=True)])
+def test_random_soups_against_brute_force(case, builder):
+    """Camera inside a cloud of small, huge, coincident and zero-area primitives: every
+    traversal kernel must agree bit for bit with brute force over all primitives."""
+    scene = soup(**case)
+    b = Renderer(scene, options={_ffi.OPT_BRUTE_FORCE: 1})
+    want_hits = b.primary_hits()
+    b.run()
+    want = b.sums()
+    b.close()
+    assert (want_hits["prim"] >= 0).mean() > 0.1
+    for tune in (0x0020, 0x1120, 0x2210, 0x4420, 0x4404):
+        r = Renderer(scene, options={_ffi.OPT_BVH_BUILDER: builder, _ffi.OPT_TUNE_TRAVERSAL: tune})
+        hits = r.primary_hits()
+        r.run()
+        got = r.sums()
+        r.close()
+        for f in ("prim", "t", "u", "v"):
+            assert np.array_equal(hits[f].view(np.uint32), want_hits[f].view(np.uint32)), (hex(tune), f)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), hex(tune)
