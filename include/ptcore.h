@@ -166,7 +166,12 @@ enum {
     PTC_OPT_TUNE_TRAVERSAL = 9,
     /* Hierarchy builder used by the next ptc_build: 0 = LBVH (Karras radix tree over
      * Morton codes), 1 = PLOC (locally-ordered clustering, better trees; default). */
-    PTC_OPT_BVH_BUILDER = 10
+    PTC_OPT_BVH_BUILDER = 10,
+    /* 1 (default) = when a scene mixes shading classes (triangle / sphere hits, Phong / GGX
+     * materials) the hits of a bounce are grouped by class before the surface kernel runs,
+     * so that the lanes of a wave take the same branches; 0 = plain path order. Results do
+     * not depend on it. */
+    PTC_OPT_GROUP_HITS = 11
 };
 
 /* ----------------------------------------------------------- entry points -- */

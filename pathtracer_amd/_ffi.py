@@ -88,6 +88,7 @@ OPT_SEMANTICS, OPT_SEEDING, OPT_BOUNCE_CAP, OPT_CULL_ZERO = 1, 2, 3, 4
 OPT_BATCH_PATHS, OPT_PROFILE, OPT_COUNT_TRAVERSAL, OPT_BRUTE_FORCE = 5, 6, 7, 8
 OPT_TUNE_TRAVERSAL = 9
 OPT_BVH_BUILDER = 10
+OPT_GROUP_HITS = 11
 
 ERR_INVALID, ERR_INTEGRATOR, ERR_DEVICE, ERR_UNSUPPORTED, ERR_NOT_BUILT = -1, -2, -3, -4, -5
 

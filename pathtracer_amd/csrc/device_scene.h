@@ -104,6 +104,7 @@ struct RenderParams {
     int32_t cull_zero;
     int32_t brute_force;
     uint32_t samples_per_path;  // shadow-ray samples per segment (integrator dependent)
+    uint32_t group_hits;        // group the hits of a bounce by shading class (mixed scenes)
     uint32_t root_light_samples;
     // traversal tuning: idle lanes that trigger a refill, 0 = one ray per thread, 1 = refilling waves + while-while rounds, 2 = refilling waves + single steps,
     // entries a wave reserves per atomic (0 = chosen from the launch size)

@@ -42,6 +42,8 @@ struct ptc_context {
     std::vector<PtcDirectionalLight> dlights;
     std::vector<PtcQuadLight> qlights;
     bool non_diffuse = false;
+    bool group_hits = true;                     // PTC_OPT_GROUP_HITS
+    bool mixed_hits = false;                    // hits fall into more than one shading class (primitive kind x BRDF)
 
     // device scene
     PtcTriangle* d_tris = nullptr;
@@ -287,6 +289,7 @@ int makeParams(ptc_context* ctx, int frame_id, uint32_t w, uint32_t h, RenderPar
     rp.brute_force = ctx->brute_force;
     rp.root_light_samples = (uint32_t)(int)sqrtf((float)ctx->light_samples);
     rp.samples_per_path = samplesPerSegment(ctx, rp.root_light_samples);
+    rp.group_hits = ctx->mixed_hits && ctx->group_hits ? 1 : 0;
     rp.tune_refill = ctx->tune_refill;
     rp.tune_mode = ctx->tune_mode;
     // shadow rays end at very different times (any hit stops them): refilling waves pay off
@@ -328,7 +331,7 @@ int runBounces(ptc_context* ctx, const RenderParams& rp, const DevScene& sc, uin
         ctx->stats.extend_launches++;
         {
             Timed t(ctx, 3);
-            wf_compact_hits(ctx->stream, rp, ctx->ps, count, ctx->hitq, grp);
+            wf_compact_hits(ctx->stream, rp, sc, ctx->ps, count, ctx->hitq, grp);
         }
         {
             Timed t(ctx, 2);
@@ -588,6 +591,14 @@ int ptc_build(ptc_context* ctx) {
     for (size_t i = 0; i < ctx->tris.size(); ++i) tmat[i] = matId(ctx->tris[i].mv, ctx->tris[i].objType);
     // spheres always report objectType OBJECT (Sphere.cu:55)
     for (size_t i = 0; i < ctx->spheres.size(); ++i) smat[i] = matId(ctx->spheres[i].mv, PTC_OBJECT);
+    {
+        // shading classes present: (triangle | sphere) x (Phong | GGX); with more than one, the
+        // hit queue is grouped by class so that the lanes of a wave run the same branches
+        bool seen[4] = {false, false, false, false};
+        for (uint32_t m : tmat) seen[mats[m & ~MAT_LIGHT_BIT].brdf_type == PTC_GGX ? 1 : 0] = true;
+        for (uint32_t m : smat) seen[2 + (mats[m & ~MAT_LIGHT_BIT].brdf_type == PTC_GGX ? 1 : 0)] = true;
+        ctx->mixed_hits = (int)seen[0] + seen[1] + seen[2] + seen[3] > 1;
+    }
     CHK(upload(ctx->d_materials, mats, ctx->stream));
     CHK(upload(ctx->d_tris, ctx->tris, ctx->stream));
     CHK(upload(ctx->d_spheres, ctx->spheres, ctx->stream));
@@ -738,6 +749,7 @@ int ptc_set_option(ptc_context* ctx, int option, int64_t value) {
         case PTC_OPT_PROFILE: ctx->profile = value != 0; break;
         case PTC_OPT_COUNT_TRAVERSAL: ctx->count_trav = value != 0; break;
         case PTC_OPT_BRUTE_FORCE: ctx->brute_force = value != 0; break;
+        case PTC_OPT_GROUP_HITS: ctx->group_hits = value != 0; break;
         case PTC_OPT_BVH_BUILDER:
             if (value != 0 && value != 1) return fail(ctx, PTC_ERR_INVALID, "BVH builder must be 0 (LBVH) or 1 (PLOC)");
             ctx->bvh_builder = (int)value;

@@ -17,7 +17,7 @@ void wf_extend(hipStream_t s, const RenderParams& rp, const DevScene& sc, const 
                uint32_t resident_waves, bool coherent, bool count_trav, unsigned long long* trav_counters);
 uint32_t wf_resident_waves(int device);
 // positions of the paths that hit something (misses end there)
-void wf_compact_hits(hipStream_t s, const RenderParams& rp, const PathState& ps, uint32_t count, uint32_t* hit_queue, uint32_t* hit_count);
+void wf_compact_hits(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, uint32_t count, uint32_t* hit_queue, uint32_t* hit_count);
 // Everything of a bounce's closest-hit programs that does not depend on shadow-ray
 // visibility: light samples (terms + shadow rays, their count in `shadow_count`), emission,
 // next direction / throughput, survivors -> the `*_next` path state, packed; segments whose radiance needs the

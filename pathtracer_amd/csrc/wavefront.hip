@@ -114,8 +114,8 @@ __device__ __forceinline__ void queue_append(bool keep, uint32_t value, uint32_t
 // atomic rate, about 88 per microsecond, is what bounds the cheap kernels).
 template <int N>
 __device__ __forceinline__ void queue_reserve_streams(const bool keep[N], uint32_t* __restrict__ counter, uint32_t at[N]) {
-    __shared__ uint32_t s_cnt[16][N];
-    __shared__ uint32_t s_base;
+    __shared__ uint32_t s_cnt[16][N];  // per wave and stream: entries, then their first position
+    __shared__ uint32_t s_tot[N];      // per stream: entries of the block, then the stream's first position
     const uint32_t lane = __lane_id();
     const uint32_t wave = threadIdx.x >> 6, nwaves = (blockDim.x + 63u) >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -128,23 +128,34 @@ __device__ __forceinline__ void queue_reserve_streams(const bool keep[N], uint32
         for (int k = 0; k < N; ++k) s_cnt[wave][k] = (uint32_t)__popcll(m[k]);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t total = 0;
-        for (int k = 0; k < N; ++k)
-            for (uint32_t w = 0; w < nwaves; ++w) total += s_cnt[w][k];
-        s_base = total ? atomicAdd(counter, total) : 0u;
+    if (threadIdx.x < (uint32_t)N) {  // one thread per stream: its total
+        uint32_t t = 0;
+        for (uint32_t w = 0; w < nwaves; ++w) t += s_cnt[w][threadIdx.x];
+        s_tot[threadIdx.x] = t;
     }
     __syncthreads();
-    uint32_t base = s_base;
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        uint32_t b = base;
-        for (uint32_t w = 0; w < nwaves; ++w) {
-            if (w < wave) b += s_cnt[w][k];
-            base += s_cnt[w][k];
+    if (threadIdx.x == 0) {  // the block's span, split among the streams
+        uint32_t total = 0;
+        for (int k = 0; k < N; ++k) total += s_tot[k];
+        uint32_t run = total ? atomicAdd(counter, total) : 0u;
+        for (int k = 0; k < N; ++k) {
+            const uint32_t t = s_tot[k];
+            s_tot[k] = run;
+            run += t;
         }
-        at[k] = b + (uint32_t)__popcll(m[k] & lt);
     }
+    __syncthreads();
+    if (threadIdx.x < (uint32_t)N) {  // one thread per stream: where each wave's entries start
+        uint32_t run = s_tot[threadIdx.x];
+        for (uint32_t w = 0; w < nwaves; ++w) {
+            const uint32_t c = s_cnt[w][threadIdx.x];
+            s_cnt[w][threadIdx.x] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; ++k) at[k] = keep[k] ? s_cnt[wave][k] + (uint32_t)__popcll(m[k] & lt) : 0u;
 }
 
 // The same for four streams at once, with one round of barriers: streams 0 and 1 go to
@@ -598,20 +609,34 @@ __global__ __launch_bounds__(BLOCK) void k_extend_brute(RenderParams rp, DevScen
 // The positions of the paths that hit something go to `hit_queue` (the only ones the
 // surface kernel looks at, so that its waves are full); a miss ends the path right here: radiance = background
 // colour, not scaled by the throughput (Common.cu:13-18).
-__global__ __launch_bounds__(GEN_BLOCK) void k_compact_hits(RenderParams rp, PathState ps, uint32_t count, uint32_t* __restrict__ hit_queue,
+#define HIT_CLASSES 4   /* (triangle | sphere) x (Phong | GGX) */
+
+// GROUP: within the block's span of the queue the hits are ordered by shading class, so
+// that (all but a few of) the surface kernel's waves see one primitive kind and one BRDF.
+template <bool GROUP>
+__global__ __launch_bounds__(GEN_BLOCK) void k_compact_hits(RenderParams rp, DevScene sc, PathState ps, uint32_t count, uint32_t* __restrict__ hit_queue,
                                                         uint32_t* __restrict__ hit_count) {
-    bool hit[GEN_CHUNKS];
-    uint32_t ps_[GEN_CHUNKS], at[GEN_CHUNKS];
+    constexpr int NS = GROUP ? GEN_CHUNKS * HIT_CLASSES : GEN_CHUNKS;
+    bool keep[NS];
+    uint32_t at[NS], idx[GEN_CHUNKS], stream[GEN_CHUNKS];
     const bool bg = rp.bg[0] != 0.f || rp.bg[1] != 0.f || rp.bg[2] != 0.f;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) keep[k] = false;
 #pragma unroll
     for (int c = 0; c < GEN_CHUNKS; ++c) {
         const uint32_t i = (blockIdx.x * GEN_CHUNKS + c) * GEN_BLOCK + threadIdx.x;
-        hit[c] = false;
-        ps_[c] = 0;
+        idx[c] = i;
+        stream[c] = NS;  // none
         if (i < count) {
-            ps_[c] = i;
-            hit[c] = ps.hit_ref[i] != HIT_MISS;
-            if (!hit[c] && bg) {
+            const int ref = ps.hit_ref[i];
+            if (ref != HIT_MISS) {
+                uint32_t cls = 0;
+                if (GROUP) {
+                    const uint32_t mat = ref >= 0 ? sc.tri_mat[ref] : sc.sph_mat[HIT_SPHERE_SLOT(ref)];
+                    cls = (ref >= 0 ? 0u : 2u) | (sc.materials[mat & ~MAT_LIGHT_BIT].brdf_type == PTC_GGX ? 1u : 0u);
+                }
+                stream[c] = cls * GEN_CHUNKS + c;
+            } else if (bg) {
                 const uint32_t p = ps.pid[i];
                 float4 L = ps.L[p];
                 L.x += rp.bg[0];
@@ -621,10 +646,21 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_compact_hits(RenderParams rp, Pat
             }
         }
     }
-    queue_reserve_streams<GEN_CHUNKS>(hit, hit_count, at);
 #pragma unroll
-    for (int c = 0; c < GEN_CHUNKS; ++c)
-        if (hit[c]) hit_queue[at[c]] = ps_[c];
+    for (int k = 0; k < NS; ++k) {
+#pragma unroll
+        for (int c = 0; c < GEN_CHUNKS; ++c) keep[k] = keep[k] || stream[c] == (uint32_t)k;
+    }
+    queue_reserve_streams<NS>(keep, hit_count, at);
+#pragma unroll
+    for (int c = 0; c < GEN_CHUNKS; ++c) {
+        if (stream[c] == NS) continue;
+        uint32_t pos = 0;
+#pragma unroll
+        for (int k = 0; k < NS; ++k)
+            if (stream[c] == (uint32_t)k) pos = at[k];
+        hit_queue[pos] = idx[c];
+    }
 }
 
 // ----------------------------------------------------------- light samples --
@@ -1499,9 +1535,11 @@ uint32_t wf_resident_waves(int device) {
 }
 
 // Queue of the paths whose extension ray hit something; misses end there.
-void wf_compact_hits(hipStream_t s, const RenderParams& rp, const PathState& ps, uint32_t count, uint32_t* hit_queue, uint32_t* hit_count) {
+void wf_compact_hits(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, uint32_t count, uint32_t* hit_queue, uint32_t* hit_count) {
     if (count == 0) return;
-    hipLaunchKernelGGL(k_compact_hits, dim3(blocks_for(count, GEN_BLOCK * GEN_CHUNKS)), dim3(GEN_BLOCK), 0, s, rp, ps, count, hit_queue, hit_count);
+    const dim3 g(blocks_for(count, GEN_BLOCK * GEN_CHUNKS)), b(GEN_BLOCK);
+    if (rp.group_hits) hipLaunchKernelGGL(k_compact_hits<true>, g, b, 0, s, rp, sc, ps, count, hit_queue, hit_count);
+    else hipLaunchKernelGGL(k_compact_hits<false>, g, b, 0, s, rp, sc, ps, count, hit_queue, hit_count);
 }
 
 // `count_ptr` (device) holds the number of queued paths; `max_count` bounds it and sizes the grid.
