@@ -273,3 +273,17 @@ def test_converged_images_match_the_reference(name, rel, tol):
     relrmse = np.sqrt(((bm - br) ** 2).mean()) / br.mean()
     assert relrmse < tol, relrmse
     assert np.allclose(mine.mean(axis=(0, 1)), ref.mean(axis=(0, 1)), rtol=0.02)
+
+
+@pytest.mark.parametrize("rel,over", [("scene4/dragon.test", dict(size="160 120", spp="2")), ("scene4/ggx.test", dict(size="160 35", spp="4")),
+                                      ("scene3/cornellRR.test", dict(size="96 96", spp="4"))])
+def test_hit_grouping_does_not_change_results(rel, over):
+    """Grouping a bounce's hits by shading class only reorders work: bit-identical sums."""
+    scene = load(rel, **over)
+    out = []
+    for group in (0, 1):
+        r = Renderer(scene, options={_ffi.OPT_SEMANTICS: 1, _ffi.OPT_SEEDING: 1, _ffi.OPT_BOUNCE_CAP: 8, _ffi.OPT_GROUP_HITS: group})
+        r.run()
+        out.append(r.sums())
+        r.close()
+    assert np.array_equal(out[0].view(np.uint32), out[1].view(np.uint32))
