@@ -3,9 +3,10 @@
 //
 // The control flow of one render is the reference's Renderer::run ->
 // context->launch (Renderer.cpp:27-37) unrolled into batches: a batch holds
-// `n` samples of every pixel; its paths are generated, then extended /
-// connected / shaded bounce by bounce while the queue of live paths shrinks,
-// and finally summed into the per-pixel radiance sums in sample order.
+// `n` samples of every pixel; its paths are generated, then bounce by bounce
+// extended, processed at their hits (light samples, next direction), shadow-tested
+// and gathered while the packed set of live paths shrinks, and finally summed into
+// the per-pixel radiance sums in sample order.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -72,7 +73,7 @@ struct ptc_context {
     uint32_t contrib_samples = 0;
     uint32_t* hitq = nullptr;                   // paths of this bounce that hit something
     uint32_t* gatherq = nullptr;                // segments of this bounce whose radiance waits for the light terms
-    uint32_t* qcount = nullptr;                 // two groups {hit, next, shadow, extend work, shadow work} used alternately, [16] generate
+    uint32_t* qcount = nullptr;                 // two groups {hit, next, shadow, extend work, shadow work, gather} used alternately, [16] generate
     uint32_t resident_waves = 6144;
     unsigned long long* counters = nullptr;     // [0..3] traversal nodes/prims (extension, shadow), [4] shadow rays
     uint32_t* h_count = nullptr;                // pinned
