@@ -287,3 +287,19 @@ def test_hit_grouping_does_not_change_results(rel, over):
         out.append(r.sums())
         r.close()
     assert np.array_equal(out[0].view(np.uint32), out[1].view(np.uint32))
+
+
+@pytest.mark.parametrize("kind,semantics", [("direct", 0), ("nee", 0), ("nee", 1), ("raytracer", 0)])
+def test_other_dragon_scenes(kind, semantics):
+    """scene 2/dragon.test (direct, 50 stratified shadow rays per path), scene 3/dragon.test
+    (path tracer, Phong, NEE + roulette) and scene 1/scene7.test (ray tracer, point light) --
+    the same geometry as scene 4/dragon.test under the other integrators."""
+    from util import dragon_variant
+    scene = SceneLoader().loadText(dragon_variant(kind, size="128 96", spp="2"))
+    r = Renderer(scene)
+    got = r.primary_hits()
+    r.close()
+    want = orc().primary_hits(scene, use_bvh=1)
+    for f in ("prim", "t", "u", "v"):
+        assert np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)), f
+    compare_render(scene, semantics=semantics, seeding=1, use_bvh=1, bounce_cap=8, min_close=0.97, max_block_rel=0.05)

@@ -162,3 +162,16 @@ def test_dragon_scene_settings():
     mats = {bytes(t.mv) for t in s.triangles}
     assert len(mats) <= 4  # 84-byte material copied into each of the 100006 triangles
     assert s.triangles[4].mv.brdf_type == 1 and s.triangles[4].mv.roughness == f32(0.1)  # 0..3 are the two quad lights
+
+
+def test_dragon_variants_rebuild_the_other_shipped_dragon_scenes():
+    from util import dragon_variant
+    d = SceneLoader().loadText(dragon_variant("direct"))
+    assert d.integratorName == "direct" and d.light_samples == 25 and d.light_stratify == 1 and len(d.qlights) == 2
+    assert len(d.triangles) == 100006 and abs(d.qlights[0].color.x - 10) < 1e-6 and d.triangles[4].mv.brdf_type == 0
+    n = SceneLoader().loadText(dragon_variant("nee"))
+    assert n.integratorName == "pathtracer" and n.samples_per_pixel == 64 and n.sampling_method == 0 and n.config.next_event_est == 1
+    assert abs(n.triangles[4].mv.diffuse.y - 0.6) < 1e-6 and abs(n.triangles[100005].mv.diffuse.x - 0.7) < 1e-6
+    r = SceneLoader().loadText(dragon_variant("raytracer"))
+    assert r.integratorName == "raytracer" and len(r.triangles) == 100000 and len(r.plights) == 1 and len(r.qlights) == 0
+    assert abs(r.triangles[0].mv.specular.x - 0.3) < 1e-6 and abs(r.config.eye.z - 20) < 1e-6

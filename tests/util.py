@@ -71,3 +71,36 @@ def close_fraction(a, b, rtol=1e-3, atol=1e-3):
     both_nan = np.isnan(a) & np.isnan(b)
     ok = (np.abs(a - b) <= atol + rtol * np.abs(b)) | both_nan
     return float(ok.all(axis=-1).mean())
+
+
+def dragon_variant(kind, **over):
+    """The other dragon scenes the reference ships, rebuilt from scenes/scene4/dragon.test
+    (same 100 006 triangles; only the commands around them differ, and 3.7 MB per copy is
+    not worth keeping): "direct" = scene 2/dragon.test (direct integrator, 25 stratified
+    samples on each of the 2 quad lights, Phong), "nee" = scene 3/dragon.test (path tracer,
+    NEE + Russian roulette, Phong, hemisphere sampling), "raytracer" = scene 1/scene7.test
+    (dragon alone, one point light, the default integrator)."""
+    import re
+    from pathtracer_amd import override_scene_text
+    t = scene_text("scene4/dragon.test")
+    drop = ["gamma", "importancesampling", "brdf", "roughness"]
+    if kind == "raytracer":
+        drop += ["integrator", "spp", "nexteventestimation", "russianroulette", "quadLight"]
+        # no floor: cut everything after the dragon's own transform block
+        cut = t.index("brdf phong")
+        t = t[:cut]
+        t = override_scene_text(t, camera="0 0 20 0 0 -1 0 1 0 45", diffuse="0.4 0.1 0.1", specular="0.3 0.3 0.3", maxverts="50001")
+        t = t.replace("maxdepth 5", "ambient 0.0 0.0 0.0\npoint 0 20 20 1 1 1\nshininess 20\nmaxdepth 5", 1)
+    for cmd in drop:
+        t = re.sub(r"(?m)^%s[ \t].*\n" % cmd, "", t)
+    if kind in ("direct", "nee"):
+        t = t.replace("quadLight  -5 10 -25  0 5 5  10 0 0  5 5 6", "quadLight  -5 10 -25  0 5 5  10 0 0  10 10 12")
+        t = t.replace("quadLight  -5 20 15  0 -5 5  10 0 0  9 9 8", "quadLight  -5 20 15  0 -5 5  10 0 0  18 18 16")
+        t = t.replace("diffuse 0.08 0.4 0.005", "diffuse 0.3 0.6 0.1\nshininess 20", 1).replace("diffuse 0.46 0.46 0.46", "diffuse 0.7 0.7 0.7", 1)
+        if kind == "direct":
+            t = re.sub(r"(?m)^(spp|nexteventestimation|russianroulette)[ \t].*\n", "", t)
+            t = override_scene_text(t, integrator="direct")
+            t = t.replace("integrator direct", "integrator direct\nlightsamples 25\nlightstratify on", 1)
+        else:
+            t = override_scene_text(t, spp="64")
+    return override_scene_text(t, **over)
