@@ -145,8 +145,10 @@ enum {
     /* 1 = stop a path once its throughput is exactly (0,0,0) (every later
      * contribution is radiance*throughput, RayTracer.cu:918). Default 1. */
     PTC_OPT_CULL_ZERO = 4,
-    /* Maximum camera paths in flight per wavefront batch (rounded to whole
-     * samples over the image). Default 67108864 (about 16 GB of path state with two light samples per segment). */
+    /* Maximum camera paths in flight per wavefront batch (rounded to whole samples over
+     * the image, and limited to what fits in half of the free device memory at about
+     * 170 + 44 x light samples bytes per path). Default 536870912 (about 140 GB with two
+     * light samples per segment): fewer, larger launches per frame. */
     PTC_OPT_BATCH_PATHS = 5,
     /* 1 = bracket every kernel class with HIP events and sum the times. */
     PTC_OPT_PROFILE = 6,

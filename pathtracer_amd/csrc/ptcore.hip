@@ -81,7 +81,7 @@ struct ptc_context {
     // options
     int semantics = 0, seeding = 0, cull_zero = 1, profile = 0, count_trav = 0, brute_force = 0;
     uint32_t bounce_cap = 1024;
-    uint64_t batch_paths = 64u << 20;
+    uint64_t batch_paths = 512u << 20;
     int bvh_builder = 1;
     uint32_t tune_refill = 24, tune_mode = 5, tune_shadow = 5, tune_chunk = 0;
 
@@ -387,7 +387,19 @@ int renderRange(ptc_context* ctx, int frame_id, uint32_t w, uint32_t h, int32_t 
     const uint32_t S = rp.samples_per_path;
     // samples of every pixel per batch
     uint64_t per_batch = rp.seeding == 0 ? 1u : std::max<uint64_t>(1u, ctx->batch_paths / ctx->npix_pad);
-    if (S) per_batch = std::max<uint64_t>(1u, std::min<uint64_t>(per_batch, (6ull << 30) / ((uint64_t)ctx->npix_pad * S * 12ull)));
+    {
+        // device memory one path of a batch takes: the packed state twice, L, hit, gather record, two
+        // queue entries, and per light sample its term and its shadow-ray record; a batch may take
+        // half of what the device has free (counting what this context already holds for paths)
+        const uint64_t per_path = 2u * (48u + 4u) + 16u + 8u + 32u + 8u + (uint64_t)S * (12u + 32u);
+        size_t free_b = 0, total_b = 0;
+        CHK(hipMemGetInfo(&free_b, &total_b));
+        const uint64_t held = (uint64_t)ctx->ps.capacity * (2u * (48u + 4u) + 16u + 8u + 32u + 8u + (uint64_t)ctx->contrib_samples * (12u + 32u));
+        const uint64_t fit = ((uint64_t)free_b + held) / 2u / per_path;
+        per_batch = std::max<uint64_t>(1u, std::min<uint64_t>(per_batch, fit / ctx->npix_pad));
+        // 32-bit indices into the per-sample arrays
+        if (S) per_batch = std::max<uint64_t>(1u, std::min<uint64_t>(per_batch, 0xFFFFFF00ull / ((uint64_t)ctx->npix_pad * S)));
+    }
     per_batch = std::min<uint64_t>(per_batch, (uint64_t)std::max(1, j1 - j0));
     if ((uint64_t)ctx->npix_pad * per_batch > 0xFFFFFFF0ull) return fail(ctx, PTC_ERR_INVALID, "batch too large");
     rc = ensurePaths(ctx, (uint32_t)(ctx->npix_pad * per_batch), S);
