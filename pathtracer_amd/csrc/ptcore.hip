@@ -271,7 +271,9 @@ int makeParams(ptc_context* ctx, int frame_id, uint32_t w, uint32_t h, RenderPar
     {
         const uint32_t tiles_x = (w + 7u) / 8u, tiles_y = (h + 7u) / 8u;
         rp.inv_tiles_x = 1.0 / (double)std::max(tiles_x, 1u);
-        rp.inv_npix_pad = 1.0 / (double)std::max(tiles_x * tiles_y * 64u, 1u);
+        (void)tiles_y;
+        rp.batch_samples = 1u;  // set per batch by renderRange
+        rp.inv_batch_samples = 1.0;
     }
     rp.cf.next_event_est = ctx->next_event_est;
     rp.light_samples = ctx->light_samples;
@@ -406,6 +408,8 @@ int renderRange(ptc_context* ctx, int frame_id, uint32_t w, uint32_t h, int32_t 
     if (rc) return rc;
     for (int32_t ja = j0; ja < j1; ja += (int32_t)per_batch) {
         const uint32_t ns = (uint32_t)std::min<int64_t>((int64_t)per_batch, j1 - ja);
+        rp.batch_samples = ns;
+        rp.inv_batch_samples = 1.0 / (double)ns;
         const uint32_t n_paths = ns * ctx->npix_pad;
         const int seedL = rp.seeding == 0 ? 1 : 0;  // reference order: result += radiance per segment
         CHK(hipMemsetAsync(ctx->qcount + 16, 0, sizeof(uint32_t), ctx->stream));
