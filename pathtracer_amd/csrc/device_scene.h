@@ -95,7 +95,7 @@ struct RenderParams {
     int32_t integrator;
     float bg[3];
     uint32_t width, height;
-    double inv_tiles_x;                // reciprocal of the number of 8x8-tile columns
+    double inv_tiles_x;                // reciprocal of the number of 64x64-pixel blocks per image row
     double inv_batch_samples;          // reciprocal of batch_samples
     uint32_t batch_samples;            // samples of every pixel in the current batch (path numbering)
     uint32_t frame_id;

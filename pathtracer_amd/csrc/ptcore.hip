@@ -145,7 +145,7 @@ int ensureTargets(ptc_context* ctx, uint32_t w, uint32_t h) {
     }
     freeTargets(ctx);
     const size_t n = (size_t)w * h;
-    const uint32_t tiles = ((w + 7u) / 8u) * ((h + 7u) / 8u);
+    const uint32_t tiles = ((w + 63u) / 64u) * ((h + 63u) / 64u) * 64u;  // whole 64x64-pixel blocks of 8x8 tiles
     CHK(hipMalloc((void**)&ctx->acc_own, n * 3 * sizeof(float)));
     CHK(hipMalloc((void**)&ctx->result, n * 3 * sizeof(float)));
     CHK(hipMalloc((void**)&ctx->segctr, (size_t)tiles * 64 * sizeof(uint32_t)));
@@ -269,9 +269,7 @@ int makeParams(ptc_context* ctx, int frame_id, uint32_t w, uint32_t h, RenderPar
     std::memset(&rp, 0, sizeof(rp));
     rp.cf = ctx->cfg;
     {
-        const uint32_t tiles_x = (w + 7u) / 8u, tiles_y = (h + 7u) / 8u;
-        rp.inv_tiles_x = 1.0 / (double)std::max(tiles_x, 1u);
-        (void)tiles_y;
+        rp.inv_tiles_x = 1.0 / (double)std::max((w + 63u) / 64u, 1u);  // 64x64-pixel blocks per row
         rp.batch_samples = 1u;  // set per batch by renderRange
         rp.inv_batch_samples = 1.0;
     }

@@ -78,13 +78,16 @@ __device__ __forceinline__ void path_split(const RenderParams& rp, uint32_t p, u
     pix = (tile << 6) | (p & 63u);
 }
 
+// Padded pixel number -> image coordinates.  64 consecutive numbers are an 8x8 pixel tile
+// (one wave traces a compact bundle of camera rays), 64 consecutive tiles an 8x8 block of
+// tiles, and the blocks go row by row: consecutive numbers stay close in both directions.
 __device__ __forceinline__ bool pixel_of(const RenderParams& rp, uint32_t pix, uint32_t& x, uint32_t& y) {
-    const uint32_t tiles_x = (rp.width + 7u) >> 3;
-    const uint32_t tile = pix >> 6, in = pix & 63u;
-    uint32_t tx;
-    const uint32_t ty = div_by(tile, tiles_x, rp.inv_tiles_x, tx);
-    x = tx * 8u + (in & 7u);
-    y = ty * 8u + (in >> 3);
+    const uint32_t blocks_x = (rp.width + 63u) >> 6;
+    const uint32_t in = pix & 63u, tile = (pix >> 6) & 63u, block = pix >> 12;
+    uint32_t bx;
+    const uint32_t by = div_by(block, blocks_x, rp.inv_tiles_x, bx);
+    x = (bx << 6) | ((tile & 7u) << 3) | (in & 7u);
+    y = (by << 6) | ((tile >> 3) << 3) | (in >> 3);
     return x < rp.width && y < rp.height;
 }
 
