@@ -641,6 +641,127 @@ void setChild(BvhNode& nd, int c, const TopEntry& e) {
     nd.child[c] = e.ref;
 }
 
+// ---- four-wide nodes ----------------------------------------------------------
+// The finished binary hierarchy, collapsed: a wide node starts with the two children of a
+// binary node and, while it has room, replaces the internal child with the largest box by
+// that child's own two children.  Child boxes are then stored on a 256-step grid of the
+// wide node's box, rounded outwards, so the wide hierarchy accepts every ray the binary
+// one accepts.  Returns false when some box cannot be represented that way (non-finite
+// coordinates) or the tree would need more stack than the traversal kernels have.
+struct WideChild {
+    uint32_t ref;
+    Box6 box;
+};
+
+float boxArea(const Box6& b) {
+    const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+
+bool collapseWide(const std::vector<BvhNode>& bin, std::vector<WideNode>& wide, uint32_t& depth_out) {
+    wide.clear();
+    depth_out = 0;
+    if (bin.empty()) return false;
+    struct Work {
+        uint32_t bin, widx, depth;
+    };
+    std::vector<Work> work;
+    wide.emplace_back();
+    work.push_back({0u, 0u, 1u});
+    auto childrenOf = [&](uint32_t b, std::vector<WideChild>& dst) {
+        const BvhNode& nd = bin[b];
+        for (int c = 0; c < 2; ++c) {
+            if (REF_KIND(nd.child[c]) == REF_EMPTY) continue;
+            WideChild w;
+            w.ref = nd.child[c];
+            const float* lo = c == 0 ? nd.lo0 : nd.lo1;
+            const float* hi = c == 0 ? nd.hi0 : nd.hi1;
+            for (int k = 0; k < 3; ++k) {
+                w.box.lo[k] = lo[k];
+                w.box.hi[k] = hi[k];
+            }
+            dst.push_back(w);
+        }
+    };
+    std::vector<WideChild> ch, tmp;
+    while (!work.empty()) {
+        const Work it = work.back();
+        work.pop_back();
+        depth_out = std::max(depth_out, it.depth);
+        ch.clear();
+        childrenOf(it.bin, ch);
+        for (;;) {
+            int pick = -1;
+            float best = -1.f;
+            for (size_t k = 0; k < ch.size(); ++k) {
+                if (REF_KIND(ch[k].ref) != REF_INTERNAL) continue;
+                tmp.clear();
+                childrenOf(REF_NODE(ch[k].ref), tmp);
+                if (ch.size() - 1 + tmp.size() > 4) continue;
+                const float a = boxArea(ch[k].box);
+                if (a > best) {
+                    best = a;
+                    pick = (int)k;
+                }
+            }
+            if (pick < 0) break;
+            tmp.clear();
+            childrenOf(REF_NODE(ch[pick].ref), tmp);
+            ch.erase(ch.begin() + pick);
+            ch.insert(ch.end(), tmp.begin(), tmp.end());
+        }
+        WideNode out;
+        std::memset(&out, 0, sizeof(out));
+        for (int c = 0; c < 4; ++c) out.child[c] = REF_EMPTY_WORD;
+        if (!ch.empty()) {
+            Box6 u = ch[0].box;
+            for (size_t k = 1; k < ch.size(); ++k) grow(u, ch[k].box);
+            float scale[3];
+            for (int k = 0; k < 3; ++k) {
+                if (!std::isfinite(u.lo[k]) || !std::isfinite(u.hi[k])) return false;
+                const double ext = (double)u.hi[k] - (double)u.lo[k];
+                int e = -100;
+                if (ext > 0.0) {
+                    int ex;
+                    const double m = std::frexp(ext / 255.0, &ex);  // ext/255 = m * 2^ex, m in [0.5, 1)
+                    e = m == 0.5 ? ex - 1 : ex;
+                }
+                e = std::min(std::max(e, -100), 100);
+                scale[k] = std::ldexp(1.0f, e);
+                if ((double)scale[k] * 255.0 < ext) return false;
+                out.origin[k] = u.lo[k];
+            }
+            out.scale_x = scale[0];
+            out.scale_y = scale[1];
+            out.scale_z = scale[2];
+            for (size_t c = 0; c < ch.size(); ++c) {
+                uint8_t* qlo[3] = {out.qlo_x, out.qlo_y, out.qlo_z};
+                uint8_t* qhi[3] = {out.qhi_x, out.qhi_y, out.qhi_z};
+                for (int k = 0; k < 3; ++k) {
+                    const double o = (double)u.lo[k], sc = (double)scale[k];
+                    double lo = std::floor(((double)ch[c].box.lo[k] - o) / sc), hi = std::ceil(((double)ch[c].box.hi[k] - o) / sc);
+                    lo = std::min(std::max(lo, 0.0), 255.0);
+                    hi = std::min(std::max(hi, 0.0), 255.0);
+                    if (o + lo * sc > (double)ch[c].box.lo[k] || o + hi * sc < (double)ch[c].box.hi[k]) return false;
+                    qlo[k][c] = (uint8_t)lo;
+                    qhi[k][c] = (uint8_t)hi;
+                }
+                if (REF_KIND(ch[c].ref) == REF_INTERNAL) {
+                    const uint32_t widx = (uint32_t)wide.size();
+                    wide.emplace_back();
+                    work.push_back({REF_NODE(ch[c].ref), widx, it.depth + 1u});
+                    out.child[c] = widx;
+                } else {
+                    out.child[c] = ch[c].ref;
+                }
+            }
+        }
+        wide[it.widx] = out;
+    }
+    // a ray's stack grows by at most three entries per level
+    return 3u * depth_out + 1u <= TRAV_LDS_STACK + TRAV_SPILL_STACK;
+}
+
 }  // namespace
 
 #define TOP_NODES 3u
@@ -755,11 +876,27 @@ std::string bvh_build(hipStream_t s, const BvhBuildInput& in, BvhBuildOutput& ou
         HIPCHK(hipMemcpyAsync(out.sph_prim, sprim.data(), sizeof(int32_t) * S, hipMemcpyHostToDevice, s));
     }
     HIPCHK(hipStreamSynchronize(s));
+
+    // 6. the four-wide version of the hierarchy
+    if (out.n_nodes) {
+        std::vector<BvhNode> h_bin(out.n_nodes);
+        HIPCHK(hipMemcpyAsync(h_bin.data(), out.nodes, sizeof(BvhNode) * out.n_nodes, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        std::vector<WideNode> h_wide;
+        uint32_t wdepth = 0;
+        if (collapseWide(h_bin, h_wide, wdepth)) {
+            HIPCHK(hipMalloc((void**)&out.wnodes, h_wide.size() * sizeof(WideNode)));
+            HIPCHK(hipMemcpyAsync(out.wnodes, h_wide.data(), h_wide.size() * sizeof(WideNode), hipMemcpyHostToDevice, s));
+            HIPCHK(hipStreamSynchronize(s));
+            out.n_wnodes = (uint32_t)h_wide.size();
+            out.wide_depth = wdepth;
+        }
+    }
     return "";
 }
 
 void bvh_free(BvhBuildOutput& o) {
-    for (void* p : {(void*)o.tri_q, (void*)o.tri_mat, (void*)o.tri_prim, (void*)o.spheres, (void*)o.sph_mat, (void*)o.sph_prim, (void*)o.nodes})
+    for (void* p : {(void*)o.tri_q, (void*)o.tri_mat, (void*)o.tri_prim, (void*)o.spheres, (void*)o.sph_mat, (void*)o.sph_prim, (void*)o.nodes, (void*)o.wnodes})
         if (p) (void)hipFree(p);
     o = BvhBuildOutput();
 }

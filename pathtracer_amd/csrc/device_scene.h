@@ -29,6 +29,25 @@ struct BvhNode {
 };
 static_assert(sizeof(BvhNode) == 64, "BVH node is 64 bytes");
 
+// ---- wide node: 64 bytes, up to four children with 8-bit boxes ----------------
+// Built from the binary tree by pulling grandchildren up (largest box first).  A child
+// box is stored on a grid of the node's own box: plane = origin + q * scale per axis,
+// q in 0..255, scale a power of two (so scale * (1/d) is exact), lower planes rounded
+// down and upper planes up.  Unused children have the reference REF_EMPTY_WORD.
+//   w0 = (origin.x, origin.y, origin.z, scale.x)
+//   w1 = (scale.y, scale.z, qlo.x[4], qlo.y[4])      [one byte per child]
+//   w2 = (qlo.z[4], qhi.x[4], qhi.y[4], qhi.z[4])
+//   w3 = (child0, child1, child2, child3)            internal: index into the wide array
+struct WideNode {
+    float origin[3];
+    float scale_x;
+    float scale_y, scale_z;
+    uint8_t qlo_x[4], qlo_y[4];
+    uint8_t qlo_z[4], qhi_x[4], qhi_y[4], qhi_z[4];
+    uint32_t child[4];
+};
+static_assert(sizeof(WideNode) == 64, "wide BVH node is 64 bytes");
+
 // Child reference encoding.
 //   kind (bits 31..30): 0 internal node, 1 triangle leaf, 2 sphere leaf, 3 empty
 //   internal: bits 29..0 = node index
@@ -79,7 +98,8 @@ struct DevScene {
     const int32_t* sph_prim;    // slot -> global primitive index (T + sphere index)
     const PtcMaterialValue* materials;
     const BvhNode* nodes;       // nodes[0] = root
-    uint32_t n_tris, n_spheres, n_nodes;
+    const WideNode* wnodes;     // the same hierarchy with four children per node; null when not built
+    uint32_t n_tris, n_spheres, n_nodes, n_wnodes;
     // lights
     const PtcPointLight* plights;
     const PtcDirectionalLight* dlights;
@@ -122,7 +142,7 @@ struct PathState {
     float4* o_seed;    // origin.xyz, seed of the coming segment (bits)
     float4* d_depth;   // direction.xyz, depth (bits)
     float4* thr;       // throughput.xyz, segment number within the path (bits)
-    uint32_t* pid;     // path number: sample-in-batch * padded pixel count + padded pixel number
+    uint32_t* pid;     // path number: ((tile * samples in batch + sample) * 64 + pixel within its 8x8 tile)
     float4* o_seed_next;
     float4* d_depth_next;
     float4* thr_next;

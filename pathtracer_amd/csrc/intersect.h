@@ -305,6 +305,95 @@ __device__ __forceinline__ uint32_t node_eval(const NodeData& nd, const TravRay&
     return trav_pop<LDS_N>(lds_stack, spill, sp);
 }
 
+
+// ---- four-wide nodes ----------------------------------------------------------
+// The box part of a wide node; the child references (w3) are read by wide_eval itself, from
+// the cache line this fetch brought in: they are needed last, and four registers fewer
+// stay occupied while the fetch is in flight.
+struct WideData {
+    uint4 w0, w1, w2;
+    const uint4* refs;
+};
+
+__device__ __forceinline__ WideData wide_fetch(const DevScene& sc, uint32_t cur) {
+    const uint4* p = reinterpret_cast<const uint4*>(sc.wnodes + REF_NODE(cur));
+    WideData n;
+    n.w0 = p[0];
+    n.w1 = p[1];
+    n.w2 = p[2];
+    n.refs = p + 3;
+    return n;
+}
+
+__device__ __forceinline__ float byte_f(uint32_t w, int c) { return (float)((w >> (8 * c)) & 0xFFu); }
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+__device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
+
+// Order two (entry distance, child) pairs by distance; the distances are non-negative
+// floats or 0xFFFFFFFF (not hit), so their bit patterns order like unsigned integers.
+__device__ __forceinline__ void wide_order(uint32_t& ka, uint32_t& ra, uint32_t& kb, uint32_t& rb) {
+    const bool sw = kb < ka;
+    const uint32_t k0 = sw ? kb : ka, k1 = sw ? ka : kb, r0 = sw ? rb : ra, r1 = sw ? ra : rb;
+    ka = k0;
+    kb = k1;
+    ra = r0;
+    rb = r1;
+}
+
+// Slab-test the (up to) four child boxes against [tmin, lim]; returns the child to visit
+// next and pushes the other hit children.  SORT: nearest first (closest-hit rays); without
+// it the children go in storage order (any-hit rays, where every hit child has to be
+// visited anyway unless an occluder turns up).
+template <bool SORT, int LDS_N = TRAV_LDS_STACK>
+__device__ __forceinline__ uint32_t wide_eval(const WideData& nd, const TravRay& r, float lim, uint32_t* lds_stack, uint32_t* spill, int& sp) {
+    // plane distance of grid coordinate q along x: (origin.x + q*scale.x - o.x)/d.x = q*sx + bx
+    const float sx = __uint_as_float(nd.w0.w) * r.ix, sy = __uint_as_float(nd.w1.x) * r.iy, sz = __uint_as_float(nd.w1.y) * r.iz;
+    const float bx = __builtin_fmaf(__uint_as_float(nd.w0.x), r.ix, r.nox), by = __builtin_fmaf(__uint_as_float(nd.w0.y), r.iy, r.noy), bz = __builtin_fmaf(__uint_as_float(nd.w0.z), r.iz, r.noz);
+    // the planes the ray enters / leaves through, per axis, for all four children at once
+    const bool px = r.ix >= 0.f, py = r.iy >= 0.f, pz = r.iz >= 0.f;
+    const uint32_t nx = px ? nd.w1.z : nd.w2.y, fx = px ? nd.w2.y : nd.w1.z;
+    const uint32_t ny = py ? nd.w1.w : nd.w2.z, fy = py ? nd.w2.z : nd.w1.w;
+    const uint32_t nz = pz ? nd.w2.x : nd.w2.w, fz = pz ? nd.w2.w : nd.w2.x;
+    const uint4 w3 = *nd.refs;
+    uint32_t key[4], ref[4] = {w3.x, w3.y, w3.z, w3.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float tn = fmaxf(max3f(__builtin_fmaf(byte_f(nx, c), sx, bx), __builtin_fmaf(byte_f(ny, c), sy, by), __builtin_fmaf(byte_f(nz, c), sz, bz)), r.tmin);
+        const float tf = fminf(min3f(__builtin_fmaf(byte_f(fx, c), sx, bx), __builtin_fmaf(byte_f(fy, c), sy, by), __builtin_fmaf(byte_f(fz, c), sz, bz)), lim);
+        key[c] = (tn <= tf && ref[c] != REF_EMPTY_WORD) ? __float_as_uint(tn) : 0xFFFFFFFFu;
+    }
+    if (SORT) {
+        wide_order(key[0], ref[0], key[1], ref[1]);
+        wide_order(key[2], ref[2], key[3], ref[3]);
+        wide_order(key[0], ref[0], key[2], ref[2]);
+        wide_order(key[1], ref[1], key[3], ref[3]);
+        wide_order(key[1], ref[1], key[2], ref[2]);
+        // nearest in [0]; farther ones are pushed first
+        if (sp + 3 <= LDS_N) {  // no branches: a child that was not hit is written above the top and not counted
+            lds_stack[sp * TRAV_BLOCK] = ref[3];
+            sp += key[3] != 0xFFFFFFFFu ? 1 : 0;
+            lds_stack[sp * TRAV_BLOCK] = ref[2];
+            sp += key[2] != 0xFFFFFFFFu ? 1 : 0;
+            lds_stack[sp * TRAV_BLOCK] = ref[1];
+            sp += key[1] != 0xFFFFFFFFu ? 1 : 0;
+        } else {
+            if (key[3] != 0xFFFFFFFFu) trav_push<LDS_N>(lds_stack, spill, sp, ref[3]);
+            if (key[2] != 0xFFFFFFFFu) trav_push<LDS_N>(lds_stack, spill, sp, ref[2]);
+            if (key[1] != 0xFFFFFFFFu) trav_push<LDS_N>(lds_stack, spill, sp, ref[1]);
+        }
+        if (key[0] != 0xFFFFFFFFu) return ref[0];
+        return trav_pop<LDS_N>(lds_stack, spill, sp);
+    }
+    uint32_t next = REF_DONE;
+#pragma unroll
+    for (int c = 3; c >= 0; --c) {
+        if (key[c] == 0xFFFFFFFFu) continue;
+        if (next != REF_DONE) trav_push<LDS_N>(lds_stack, spill, sp, next);
+        next = ref[c];
+    }
+    return next != REF_DONE ? next : trav_pop<LDS_N>(lds_stack, spill, sp);
+}
+
 // Visit one internal node.
 template <bool COUNT, int LDS_N = TRAV_LDS_STACK>
 __device__ __forceinline__ uint32_t trav_node(const DevScene& sc, const TravRay& r, uint32_t cur, float lim, uint32_t* lds_stack, uint32_t* spill, int& sp,

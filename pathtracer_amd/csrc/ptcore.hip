@@ -250,6 +250,8 @@ DevScene deviceScene(const ptc_context* c) {
     sc.sph_prim = c->bvh.sph_prim;
     sc.materials = c->d_materials;
     sc.nodes = c->bvh.nodes;
+    sc.wnodes = c->bvh.wnodes;
+    sc.n_wnodes = c->bvh.n_wnodes;
     sc.n_tris = (uint32_t)c->tris.size();
     sc.n_spheres = (uint32_t)c->spheres.size();
     sc.n_nodes = c->bvh.n_nodes;

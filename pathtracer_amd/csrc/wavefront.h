@@ -56,6 +56,9 @@ struct BvhBuildOutput {  // device allocations owned by the caller afterwards
     BvhNode* nodes = nullptr;
     uint32_t n_nodes = 0;
     uint32_t max_depth = 0;
+    WideNode* wnodes = nullptr;  // four-wide version of the hierarchy; null when it could not be built
+    uint32_t n_wnodes = 0;
+    uint32_t wide_depth = 0;
 };
 
 // Returns an empty string on success, else an error message.

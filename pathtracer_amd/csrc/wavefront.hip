@@ -473,7 +473,7 @@ __device__ __forceinline__ void deferred_item(const DevScene& sc, DeferredLds& L
 #ifndef DQ_MIN_WAVES
 #define DQ_MIN_WAVES 6   /* waves per SIMD the register allocation aims at (LDS allows 6 blocks per CU) */
 #endif
-template <bool ANY, bool COUNT>
+template <bool ANY, bool COUNT, bool WIDE>
 __global__ __launch_bounds__(BLOCK, DQ_MIN_WAVES) void k_trace_deferred(RenderParams rp, DevScene sc, PathState ps,
                                                           const uint32_t* __restrict__ count_ptr, uint32_t count_arg,
                                                           uint32_t* __restrict__ work_counter, uint32_t wave_chunk,
@@ -565,7 +565,11 @@ __global__ __launch_bounds__(BLOCK, DQ_MIN_WAVES) void k_trace_deferred(RenderPa
             do_node = false;
         }
         NodeData nd;
-        if (do_node) nd = node_fetch(sc, cur);
+        WideData wd;
+        if (do_node) {
+            if (WIDE) wd = wide_fetch(sc, cur);
+            else nd = node_fetch(sc, cur);
+        }
         // ---- ... run the full batches of queued tests while it is in flight, ...
         if (qn >= 64u) {
             wave_lds_sync();
@@ -580,7 +584,7 @@ __global__ __launch_bounds__(BLOCK, DQ_MIN_WAVES) void k_trace_deferred(RenderPa
         if (do_node) {
             if (COUNT) cnt.nodes++;
             const float lim = ANY ? r.tmax : u2f((uint32_t)(L.best[tid] >> 32));
-            cur = node_eval<DQ_STACK>(nd, r, lim, my_stack, spill, sp);
+            cur = WIDE ? wide_eval<!ANY, DQ_STACK>(wd, r, lim, my_stack, spill, sp) : node_eval<DQ_STACK>(nd, r, lim, my_stack, spill, sp);
         }
         // ---- leaves: queue their primitives, carry on with the stack
         const uint32_t kind = REF_KIND(cur);
@@ -1480,7 +1484,7 @@ static uint32_t deferred_resident_waves() {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (cache[dev] == 0u) {
         int per_cu = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_deferred<false, false>, BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 3;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace_deferred<false, false, false>, BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 3;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
         cache[dev] = (uint32_t)per_cu * (uint32_t)cus * (BLOCK / 64);
     }
@@ -1498,7 +1502,9 @@ void wf_extend(hipStream_t s, const RenderParams& rp, const DevScene& sc, const 
     uint32_t blocks, wave_chunk;
     // mode 5 (default): static for camera rays and for scenes whose whole hierarchy is a
     // handful of nodes (every ray does the same few steps), deferred tests otherwise
-    uint32_t mode = rp.tune_mode == 3 ? (coherent ? 0u : 1u) : rp.tune_mode == 5 ? ((coherent || sc.n_nodes <= TINY_BVH_NODES) ? 0u : 4u) : rp.tune_mode;
+    uint32_t mode = rp.tune_mode == 3 ? (coherent ? 0u : 1u) : rp.tune_mode == 5 ? ((coherent || sc.n_nodes <= TINY_BVH_NODES) ? 0u : 6u) : rp.tune_mode;
+    const bool wide = mode == 6 && sc.wnodes != nullptr;  // mode 6: deferred tests over the four-wide nodes
+    if (mode == 6) mode = 4;
     if (mode == 4 && !deferred_fits(sc)) mode = 1;
     trav_geometry(count, mode == 4 ? deferred_resident_waves() : resident_waves, rp.tune_chunk, blocks, wave_chunk);
     // mode 3: camera rays arrive in 8x8 pixel bundles and finish together, one ray per
@@ -1506,10 +1512,14 @@ void wf_extend(hipStream_t s, const RenderParams& rp, const DevScene& sc, const 
     // (mode 5: the same with deferred primitive tests for the scattered rays)
     if (rp.brute_force)
         hipLaunchKernelGGL(k_extend_brute, dim3(blocks_for(count)), dim3(BLOCK), 0, s, rp, sc, ps, count);
+    else if (mode == 4 && wide && count_trav)
+        hipLaunchKernelGGL((k_trace_deferred<false, true, true>), dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, nullptr, count, work_counter, wave_chunk, trav_counters, nullptr);
+    else if (mode == 4 && wide)
+        hipLaunchKernelGGL((k_trace_deferred<false, false, true>), dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, nullptr, count, work_counter, wave_chunk, trav_counters, nullptr);
     else if (mode == 4 && count_trav)
-        hipLaunchKernelGGL((k_trace_deferred<false, true>), dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, nullptr, count, work_counter, wave_chunk, trav_counters, nullptr);
+        hipLaunchKernelGGL((k_trace_deferred<false, true, false>), dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, nullptr, count, work_counter, wave_chunk, trav_counters, nullptr);
     else if (mode == 4)
-        hipLaunchKernelGGL((k_trace_deferred<false, false>), dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, nullptr, count, work_counter, wave_chunk, trav_counters, nullptr);
+        hipLaunchKernelGGL((k_trace_deferred<false, false, false>), dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, nullptr, count, work_counter, wave_chunk, trav_counters, nullptr);
     else if (mode == 0 && count_trav)
         hipLaunchKernelGGL(k_extend_static<true>, dim3(blocks_for(count)), dim3(BLOCK), 0, s, rp, sc, ps, count, trav_counters);
     else if (mode == 0)
@@ -1525,15 +1535,21 @@ void wf_shadow(hipStream_t s, const RenderParams& rp, const DevScene& sc, const 
                uint32_t* work_counter, uint32_t resident_waves, bool count_trav, unsigned long long* trav_counters, unsigned long long* shadow_total) {
     if (max_rays == 0) return;
     uint32_t blocks, wave_chunk;
-    uint32_t smode = rp.tune_shadow == 5 ? (sc.n_nodes <= TINY_BVH_NODES ? 0u : 4u) : rp.tune_shadow;
+    uint32_t smode = rp.tune_shadow == 5 ? (sc.n_nodes <= TINY_BVH_NODES ? 0u : 6u) : rp.tune_shadow;
+    const bool wide = smode == 6 && sc.wnodes != nullptr;
+    if (smode == 6) smode = 4u;
     if (smode == 4 && !deferred_fits(sc)) smode = 1u;
     trav_geometry(max_rays, smode == 4 ? deferred_resident_waves() : resident_waves, rp.tune_chunk, blocks, wave_chunk);
     if (rp.brute_force)
         hipLaunchKernelGGL(k_shadow_brute, dim3(blocks_for(max_rays)), dim3(BLOCK), 0, s, rp, sc, ps, count_ptr, shadow_total);
+    else if (smode == 4 && wide && count_trav)
+        hipLaunchKernelGGL((k_trace_deferred<true, true, true>), dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, count_ptr, 0u, work_counter, wave_chunk, trav_counters, shadow_total);
+    else if (smode == 4 && wide)
+        hipLaunchKernelGGL((k_trace_deferred<true, false, true>), dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, count_ptr, 0u, work_counter, wave_chunk, trav_counters, shadow_total);
     else if (smode == 4 && count_trav)
-        hipLaunchKernelGGL((k_trace_deferred<true, true>), dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, count_ptr, 0u, work_counter, wave_chunk, trav_counters, shadow_total);
+        hipLaunchKernelGGL((k_trace_deferred<true, true, false>), dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, count_ptr, 0u, work_counter, wave_chunk, trav_counters, shadow_total);
     else if (smode == 4)
-        hipLaunchKernelGGL((k_trace_deferred<true, false>), dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, count_ptr, 0u, work_counter, wave_chunk, trav_counters, shadow_total);
+        hipLaunchKernelGGL((k_trace_deferred<true, false, false>), dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, count_ptr, 0u, work_counter, wave_chunk, trav_counters, shadow_total);
     else if (smode == 0 && count_trav)
         hipLaunchKernelGGL(k_shadow_static<true>, dim3(blocks_for(max_rays)), dim3(BLOCK), 0, s, rp, sc, ps, count_ptr, trav_counters, shadow_total);
     else if (smode == 0)

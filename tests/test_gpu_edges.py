@@ -124,7 +124,7 @@ def test_exact_ties_go_to_the_lowest_primitive_index():
     text = ("size 48 48\nintegrator raytracer\ncamera 0 0 4 0 0 0 0 1 0 50\npoint 0 0 5 1 1 1\nmaxverts 3\n"
             "vertex -1 -1 0\nvertex 1 -1 0\nvertex 0 1 0\ndiffuse 1 0 0\ntri 0 1 2\ndiffuse 0 1 0\ntri 0 1 2\ndiffuse 0 0 1\ntri 0 1 2\n")
     scene = SceneLoader().loadText(text)
-    for tune in (0x0020, 0x1120, 0x4420, 0x5518):
+    for tune in (0x0020, 0x1120, 0x4420, 0x5518, 0x6620, 0x6604):
         hits, _ = hits_equal(scene, {_ffi.OPT_TUNE_TRAVERSAL: tune})
         assert set(np.unique(hits["prim"])) == {-1, 0}
 
@@ -228,7 +228,7 @@ def test_random_soups_against_brute_force(case, builder):
     want = b.sums()
     b.close()
     assert (want_hits["prim"] >= 0).mean() > 0.1
-    for tune in (0x0020, 0x1120, 0x2210, 0x4420, 0x4404):
+    for tune in (0x0020, 0x1120, 0x2210, 0x4420, 0x4404, 0x6620, 0x6604):
         r = Renderer(scene, options={_ffi.OPT_BVH_BUILDER: builder, _ffi.OPT_TUNE_TRAVERSAL: tune})
         hits = r.primary_hits()
         r.run()

@@ -205,7 +205,7 @@ def test_bvh_builders_agree():
     assert np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
 
 
-@pytest.mark.parametrize("tune", [0x0020, 0x1120, 0x2220, 0x4420, 0x4408, 0x4440, 0x1320])
+@pytest.mark.parametrize("tune", [0x0020, 0x1120, 0x2220, 0x4420, 0x4408, 0x4440, 0x1320, 0x6620, 0x6608, 0x6640])
 @pytest.mark.parametrize("rel,over", [("scene4/dragon.test", dict(size="160 120", spp="2")),
                                       ("scene3/cornellRR.test", dict(size="96 96", spp="4")),
                                       ("scene2/sphere.test", dict(size="160 120"))])
