@@ -584,7 +584,13 @@ __global__ __launch_bounds__(BLOCK, DQ_MIN_WAVES) void k_trace_deferred(RenderPa
         if (do_node) {
             if (COUNT) cnt.nodes++;
             const float lim = ANY ? r.tmax : u2f((uint32_t)(L.best[tid] >> 32));
-            cur = WIDE ? wide_eval<!ANY, DQ_STACK>(wd, r, lim, my_stack, spill, sp) : node_eval<DQ_STACK>(nd, r, lim, my_stack, spill, sp);
+            if (WIDE) {
+                // the origin comes from LDS, where the queued tests read it: six registers fewer than keeping -o/d
+                const float2 r0 = L.ray[0][tid];
+                cur = wide_eval<!ANY, DQ_STACK>(wd, r, mk3(r0.x, r0.y, L.ray[1][tid].x), lim, my_stack, spill, sp);
+            } else {
+                cur = node_eval<DQ_STACK>(nd, r, lim, my_stack, spill, sp);
+            }
         }
         // ---- leaves: queue their primitives, carry on with the stack
         const uint32_t kind = REF_KIND(cur);

@@ -7,7 +7,7 @@ name=$1; shift
 out=pathtracer_amd/_lib/variants; tmp=build/variant_$name
 mkdir -p $out $tmp
 for f in wavefront bvh_build ptcore; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -Ipathtracer_amd/csrc -Wno-unused-function "$@" \
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Iinclude -Ipathtracer_amd/csrc -Wno-unused-function "$@" \
     -c pathtracer_amd/csrc/$f.hip -o $tmp/$f.o &
 done
 wait
