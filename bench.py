@@ -151,8 +151,8 @@ def main():
     ext_rays, shadow_rays, paths = (float(x) for x in counts)
 
     if rank == 0:
-        # Extension-ray traversal (k_extend_static for camera rays, k_trace_deferred<false>
-        # for later bounces) is the dominant kernel class.  Algorithmic bytes per extension ray: the
+        # Extension-ray traversal (k_trace_deferred<false>; k_extend_static for tiny hierarchies)
+        # is the kernel class the roofline is quoted on.  Algorithmic bytes per extension ray: the
         # queue entry (4 B) and the ray (2 x float4 = 32 B) read, the hit (t + ref = 8 B)
         # written, 64 B per BVH node visited and 48 B per triangle tested.  The shadow-ray
         # kernel is reported the same way (32 B ray record read, 12 B written when occluded).
@@ -168,7 +168,7 @@ def main():
             if t.get("workload") == args.workload and "extend" in t:
                 traffic = round(t["extend"]["fetch_bytes_per_launch"] + t["extend"]["write_bytes_per_launch"], 1)
         roofline = {
-            "bound": "hbm", "kernel": "extension-ray traversal (k_extend_static for camera rays and tiny hierarchies, k_trace_deferred<false> otherwise)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "bound": "hbm", "kernel": "extension-ray traversal (k_trace_deferred<false> over four-wide nodes; k_extend_static for hierarchies of at most 64 nodes)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "algorithmic_bytes_per_launch": round(b_ext * st.extension_rays / launches, 1),
             "bytes_per_ray": round(b_ext, 1), "nodes_per_ray": round(nodes_per_ray, 2), "prims_per_ray": round(prims_per_ray, 2),

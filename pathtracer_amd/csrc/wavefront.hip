@@ -5,12 +5,13 @@
 //   k_extend_static / k_extend
 //                closest hit of every active path (rtTrace ray type 0:
 //                Triangle.cu / Sphere.cu over the BVH); LDS-resident stack.
-//                The static kernel (one ray per lane, tight loop) serves the
-//                coherent camera rays; the refilling kernel serves scattered
-//                rays: resident waves reserve spans of the queue from one global
+//                The static kernel (one ray per lane, tight loop) serves
+//                hierarchies of a handful of nodes; in the refilling kernel
+//                resident waves reserve spans of the queue from one global
 //                counter and lanes that finish pull the next ray of the span
 //   k_trace_deferred<false>  refilling waves whose lanes queue leaf primitives in
-//                LDS and test them 64 at a time (scattered extension rays by default)
+//                LDS and test them 64 at a time, over two-child or four-wide
+//                nodes (the default for every hierarchy that is not tiny)
 //   k_surface    one thread per path after the extension: a miss ends the path
 //                with the background colour (Common.cu:13-18); at a hit, the part of
 //                the chosen integrator's closest-hit program (RayTracer.cu) that
@@ -1506,16 +1507,16 @@ void wf_extend(hipStream_t s, const RenderParams& rp, const DevScene& sc, const 
                unsigned long long* trav_counters) {
     if (count == 0) return;
     uint32_t blocks, wave_chunk;
-    // mode 5 (default): static for camera rays and for scenes whose whole hierarchy is a
-    // handful of nodes (every ray does the same few steps), deferred tests otherwise
-    uint32_t mode = rp.tune_mode == 3 ? (coherent ? 0u : 1u) : rp.tune_mode == 5 ? ((coherent || sc.n_nodes <= TINY_BVH_NODES) ? 0u : 6u) : rp.tune_mode;
+    // mode 5 (default): static for scenes whose whole hierarchy is a handful of nodes (every
+    // ray does the same few steps), deferred tests over the four-wide nodes otherwise -- for
+    // the camera rays as well (5 % faster than the static kernel on the dragon)
+    uint32_t mode = rp.tune_mode == 3 ? (coherent ? 0u : 1u) : rp.tune_mode == 5 ? (sc.n_nodes <= TINY_BVH_NODES ? 0u : 6u) : rp.tune_mode;
     const bool wide = mode == 6 && sc.wnodes != nullptr;  // mode 6: deferred tests over the four-wide nodes
     if (mode == 6) mode = 4;
     if (mode == 4 && !deferred_fits(sc)) mode = 1;
     trav_geometry(count, mode == 4 ? deferred_resident_waves() : resident_waves, rp.tune_chunk, blocks, wave_chunk);
-    // mode 3: camera rays arrive in 8x8 pixel bundles and finish together, one ray per
-    // thread is fastest; scattered rays finish at very different times, refilling pays
-    // (mode 5: the same with deferred primitive tests for the scattered rays)
+    // mode 3: static for the camera rays (8x8 pixel bundles that finish together), refilling
+    // rounds for the scattered rays, which finish at very different times
     if (rp.brute_force)
         hipLaunchKernelGGL(k_extend_brute, dim3(blocks_for(count)), dim3(BLOCK), 0, s, rp, sc, ps, count);
     else if (mode == 4 && wide && count_trav)
