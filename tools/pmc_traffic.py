@@ -16,6 +16,16 @@ import os
 import sys
 
 
+def counting_variant(name):
+    """k_trace_deferred<ANY, COUNT, WIDE>: second argument; the other traversal kernels: <COUNT> or <COUNT, ...>."""
+    if "<" not in name:
+        return False
+    args = [a.strip() for a in name[name.index("<") + 1:name.rindex(">")].split(",")]
+    if "k_trace_deferred" in name:
+        return len(args) > 1 and args[1] == "true"
+    return args[0] == "true"
+
+
 def main():
     d, workload, out = sys.argv[1:4]
     tot = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -23,7 +33,7 @@ def main():
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"]
-            if "true>" in name:  # the counting variants run outside the timed region
+            if counting_variant(name):  # run outside the timed region
                 continue
             if "k_extend" in name or "k_trace_deferred<false" in name:
                 key = "extend"
