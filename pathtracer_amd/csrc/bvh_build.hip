@@ -264,6 +264,9 @@ __global__ void k_ploc_nn(const int* __restrict__ cluster, int m, const Box6* __
             bj = j;
         }
     }
+    // no neighbour with a finite union area (astronomically large or non-finite boxes): pair up by
+    // position, which still merges mutual pairs and so keeps the clustering moving
+    if (bj < 0 && m > 1) bj = (i ^ 1) < m ? (i ^ 1) : i - 1;
     nn[i] = bj;
 }
 

@@ -237,3 +237,38 @@ def test_random_soups_against_brute_force(case, builder):
         for f in ("prim", "t", "u", "v"):
             assert np.array_equal(hits[f].view(np.uint32), want_hits[f].view(np.uint32)), (hex(tune), f)
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), hex(tune)
+
+
+@pytest.mark.parametrize("far", ["1e30", "3e38"])
+def test_extreme_coordinates_against_brute_force(far):
+    """A small soup in front of a backdrop triangle with astronomically large coordinates.  With
+    1e30 the four-wide nodes near the root get grid steps of 2^92; with 3e38 a node's extent cannot
+    be represented on its 8-bit grid at all and the build keeps the two-child hierarchy only.
+    Either way every traversal kernel agrees bit for bit with brute force."""
+    rng = np.random.default_rng(5)
+    lines = ["size 64 48", "integrator raytracer", "maxdepth 2", "camera 0 0 3 0 0 -1 0 1 0 60", "point 0 2 3 1 1 1", "diffuse 0.5 0.5 0.5", "maxverts 2000"]
+    verts, tris = [], []
+    for i in range(400):
+        c = rng.uniform(-1.5, 1.5, 3)
+        for _ in range(3):
+            v = c + rng.uniform(-0.1, 0.1, 3)
+            verts.append(f"vertex {v[0]:.5f} {v[1]:.5f} {v[2]:.5f}")
+        tris.append(f"tri {3 * i} {3 * i + 1} {3 * i + 2}")
+    verts += [f"vertex -{far} -{far} -{far}", f"vertex {far} -{far} -{far}", f"vertex 0 {far} -{far}"]
+    tris.append("tri 1200 1201 1202")
+    scene = SceneLoader().loadText("\n".join(lines + verts + tris) + "\n")
+    b = Renderer(scene, options={_ffi.OPT_BRUTE_FORCE: 1})
+    want_hits = b.primary_hits()
+    b.run()
+    want = b.sums()
+    b.close()
+    assert (want_hits["prim"] >= 0).mean() > 0.05
+    for tune in (0x0020, 0x4420, 0x6620, 0x5518):
+        r = Renderer(scene, options={_ffi.OPT_TUNE_TRAVERSAL: tune})
+        hits = r.primary_hits()
+        r.run()
+        got = r.sums()
+        r.close()
+        for f in ("prim", "t", "u", "v"):
+            assert np.array_equal(hits[f].view(np.uint32), want_hits[f].view(np.uint32)), (hex(tune), f)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), hex(tune)
