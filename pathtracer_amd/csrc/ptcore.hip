@@ -65,6 +65,7 @@ struct ptc_context {
     size_t acc_ext_bytes = 0;
     float* result = nullptr;
     uint32_t* segctr = nullptr;
+    uint32_t* pixseed = nullptr;                // per padded pixel: start of its jitter stream in the current frame
     int32_t ref_next_sample = 0;  // reference seeding: the sample the per-pixel history is at
     PtcHitRecord* d_hits = nullptr;
 
@@ -119,10 +120,11 @@ hipError_t upload(T*& dst, const std::vector<T>& src, hipStream_t s) {
 }
 
 void freeTargets(ptc_context* c) {
-    for (void* p : {(void*)c->acc_own, (void*)c->result, (void*)c->segctr, (void*)c->d_hits})
+    for (void* p : {(void*)c->acc_own, (void*)c->result, (void*)c->segctr, (void*)c->pixseed, (void*)c->d_hits})
         if (p) (void)hipFree(p);
     c->acc_own = c->result = nullptr;
     c->segctr = nullptr;
+    c->pixseed = nullptr;
     c->d_hits = nullptr;
     c->width = c->height = c->npix_pad = 0;
 }
@@ -149,6 +151,7 @@ int ensureTargets(ptc_context* ctx, uint32_t w, uint32_t h) {
     CHK(hipMalloc((void**)&ctx->acc_own, n * 3 * sizeof(float)));
     CHK(hipMalloc((void**)&ctx->result, n * 3 * sizeof(float)));
     CHK(hipMalloc((void**)&ctx->segctr, (size_t)tiles * 64 * sizeof(uint32_t)));
+    CHK(hipMalloc((void**)&ctx->pixseed, (size_t)tiles * 64 * sizeof(uint32_t)));
     CHK(hipMalloc((void**)&ctx->d_hits, n * sizeof(PtcHitRecord)));
     CHK(hipMemsetAsync(ctx->acc_own, 0, n * 3 * sizeof(float), ctx->stream));
     CHK(hipMemsetAsync(ctx->result, 0, n * 3 * sizeof(float), ctx->stream));
@@ -415,7 +418,7 @@ int renderRange(ptc_context* ctx, int frame_id, uint32_t w, uint32_t h, int32_t 
         CHK(hipMemsetAsync(ctx->qcount + 16, 0, sizeof(uint32_t), ctx->stream));
         {
             Timed t(ctx, 3);
-            wf_generate(ctx->stream, rp, ctx->ps, ctx->npix_pad, n_paths, (uint32_t)ja, ctx->acc, ctx->segctr, seedL, ctx->qcount + 16);
+            wf_generate(ctx->stream, rp, ctx->ps, ctx->npix_pad, n_paths, (uint32_t)ja, ctx->acc, ctx->segctr, ctx->pixseed, seedL, ctx->qcount + 16);
         }
         CHK(hipMemcpyAsync(ctx->h_count, ctx->qcount + 16, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         CHK(hipStreamSynchronize(ctx->stream));
@@ -693,7 +696,7 @@ int ptc_primary_hits(ptc_context* ctx, uint32_t width, uint32_t height, PtcHitRe
     const DevScene sc = deviceScene(ctx);
     CHK(hipMemsetAsync(ctx->qcount, 0, N_QCOUNT * sizeof(uint32_t), ctx->stream));
     CHK(hipMemsetAsync(ctx->ps.hit_ref, 0xFF, (size_t)ctx->npix_pad * sizeof(int32_t), ctx->stream));  // HIT_MISS
-    wf_generate(ctx->stream, rp, ctx->ps, ctx->npix_pad, ctx->npix_pad, 0u, ctx->acc, ctx->segctr, 0, ctx->qcount + 16);
+    wf_generate(ctx->stream, rp, ctx->ps, ctx->npix_pad, ctx->npix_pad, 0u, ctx->acc, ctx->segctr, ctx->pixseed, 0, ctx->qcount + 16);
     CHK(hipMemcpyAsync(ctx->h_count, ctx->qcount + 16, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     CHK(hipStreamSynchronize(ctx->stream));
     wf_extend(ctx->stream, rp, sc, ctx->ps, *ctx->h_count, ctx->qcount + 3, ctx->resident_waves, true, false, ctx->counters);

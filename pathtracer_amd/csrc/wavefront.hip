@@ -231,9 +231,18 @@ __device__ __forceinline__ uint32_t segment_seed(const RenderParams& rp, uint32_
 // ---------------------------------------------------------------- generate --
 #define GEN_CHUNKS 4   /* chunks of GEN_BLOCK queue entries per block of k_compact_hits */
 
+// Start of every pixel's jitter stream, tea<16>(index * frameID, 0) (PinholeCamera.cu:23-24): the same
+// for all samples of the pixel, so it is computed once per frame and not once per path.
+__global__ __launch_bounds__(BLOCK) void k_pixel_seeds(RenderParams rp, uint32_t npix_pad, uint32_t* __restrict__ pixseed) {
+    const uint32_t pix = blockIdx.x * BLOCK + threadIdx.x;
+    if (pix >= npix_pad) return;
+    uint32_t x, y;
+    pixseed[pix] = pixel_of(rp, pix, x, y) ? tea16((x * rp.height + y) * rp.frame_id, 0u) : 0u;
+}
+
 __global__ __launch_bounds__(GEN_BLOCK) void k_generate(RenderParams rp, PathState ps, uint32_t npix_pad, uint32_t n_paths, uint32_t sample_begin,
-                                                    const float* __restrict__ acc, uint32_t* __restrict__ segctr, int seed_L_from_acc,
-                                                    uint32_t* __restrict__ qcount) {
+                                                    const float* __restrict__ acc, uint32_t* __restrict__ segctr, const uint32_t* __restrict__ pixseed,
+                                                    int seed_L_from_acc, uint32_t* __restrict__ qcount) {
     const uint32_t p = blockIdx.x * GEN_BLOCK + threadIdx.x;
     bool valid = p < n_paths;
     uint32_t x = 0, y = 0, pix = 0, j = 0;
@@ -250,7 +259,7 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_generate(RenderParams rp, PathSta
         const uint32_t key0 = index * rp.frame_id;
         float jx = 0.5f, jy = 0.5f;  // :47-48
         if (j != 0) {
-            uint32_t st = lcg_skip(tea16(key0, 0u), 2u * (j - 1u));
+            uint32_t st = lcg_skip(pixseed[pix], 2u * (j - 1u));
             jx = rnd(st);
             jy = rnd(st);
         }
@@ -1467,8 +1476,9 @@ __global__ __launch_bounds__(BLOCK) void k_hit_records(RenderParams rp, DevScene
 static inline uint32_t blocks_for(uint64_t n, uint32_t block = BLOCK) { return (uint32_t)((n + block - 1) / block); }
 
 void wf_generate(hipStream_t s, const RenderParams& rp, const PathState& ps, uint32_t npix_pad, uint32_t n_paths, uint32_t sample_begin,
-                 const float* acc, uint32_t* segctr, int seed_L_from_acc, uint32_t* qcount) {
-    hipLaunchKernelGGL(k_generate, dim3(blocks_for(n_paths, GEN_BLOCK)), dim3(GEN_BLOCK), 0, s, rp, ps, npix_pad, n_paths, sample_begin, acc, segctr,
+                 const float* acc, uint32_t* segctr, uint32_t* pixseed, int seed_L_from_acc, uint32_t* qcount) {
+    hipLaunchKernelGGL(k_pixel_seeds, dim3(blocks_for(npix_pad)), dim3(BLOCK), 0, s, rp, npix_pad, pixseed);
+    hipLaunchKernelGGL(k_generate, dim3(blocks_for(n_paths, GEN_BLOCK)), dim3(GEN_BLOCK), 0, s, rp, ps, npix_pad, n_paths, sample_begin, acc, segctr, pixseed,
                        seed_L_from_acc, qcount);
 }
 
