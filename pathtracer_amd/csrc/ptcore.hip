@@ -342,7 +342,7 @@ int runBounces(ptc_context* ctx, const RenderParams& rp, const DevScene& sc, uin
         {
             Timed t(ctx, 2);
             wf_surface(ctx->stream, rp, sc, ctx->ps, ctx->hitq, grp, count, ctx->npix_pad, sample_begin, ctx->segctr, grp + 1, ctx->gatherq,
-                       grp + 5, grp + 2);
+                       grp + 5, grp + 2, bounce == 0);
         }
         if (S) {
             {

@@ -25,7 +25,7 @@ void wf_compact_hits(hipStream_t s, const RenderParams& rp, const DevScene& sc, 
 // surface / shadow / gather read their queue length from device memory; `max_*` sizes the grid
 void wf_surface(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, const uint32_t* count_ptr,
                 uint32_t max_count, uint32_t npix_pad, uint32_t sample_begin, uint32_t* segctr, uint32_t* next_count,
-                uint32_t* gather_queue, uint32_t* gather_count, uint32_t* shadow_count);
+                uint32_t* gather_queue, uint32_t* gather_count, uint32_t* shadow_count, bool first_bounce /* camera segments: throughput 1 is implied */);
 void wf_shadow(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* count_ptr, uint64_t max_rays,
                uint32_t* work_counter, uint32_t resident_waves, bool count_trav, unsigned long long* trav_counters, unsigned long long* shadow_total);
 void wf_gather(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* gather_queue, const uint32_t* gather_count,

@@ -270,7 +270,6 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_generate(RenderParams rp, PathSta
         const uint32_t seed = segment_seed(rp, key0, j, 0u, segctr, pix);
         ps.o_seed[at] = make_float4(cf.eye.x, cf.eye.y, cf.eye.z, u2f(seed));
         ps.d_depth[at] = make_float4(dir.x, dir.y, dir.z, u2f(0u));
-        ps.thr[at] = make_float4(1.f, 1.f, 1.f, u2f(0u));
         ps.pid[at] = p;
         float4 L = make_float4(0.f, 0.f, 0.f, 0.f);
         if (seed_L_from_acc) {
@@ -1251,7 +1250,7 @@ __global__ __launch_bounds__(SURF_BLOCK) void k_surface(RenderParams rp, DevScen
                                                        const uint32_t* __restrict__ count_ptr, uint32_t npix_pad, uint32_t sample_begin, uint32_t* __restrict__ segctr,
                                                        uint32_t* __restrict__ next_count,
                                                        uint32_t* __restrict__ gather_queue, uint32_t* __restrict__ gather_count,
-                                                       uint32_t* __restrict__ shadow_count) {
+                                                       uint32_t* __restrict__ shadow_count, uint32_t first_bounce) {
     const uint32_t count = *count_ptr;  // hits of this bounce, written by k_compact_hits
     if (blockIdx.x * SURF_BLOCK >= count) return;
     const uint32_t i = blockIdx.x * SURF_BLOCK + threadIdx.x;
@@ -1265,7 +1264,8 @@ __global__ __launch_bounds__(SURF_BLOCK) void k_surface(RenderParams rp, DevScen
     if (hit) {
         at_state = queue[i];
         p = ps.pid[at_state];
-        const float4 o4 = ps.o_seed[at_state], d4 = ps.d_depth[at_state], t4 = ps.thr[at_state];
+        // camera segments: throughput 1, segment 0 (k_generate does not write them)
+        const float4 o4 = ps.o_seed[at_state], d4 = ps.d_depth[at_state], t4 = first_bounce ? make_float4(1.f, 1.f, 1.f, u2f(0u)) : ps.thr[at_state];
         sg.o = mk3(o4.x, o4.y, o4.z);
         sg.d = mk3(d4.x, d4.y, d4.z);
         sg.thr = mk3(t4.x, t4.y, t4.z);
@@ -1596,10 +1596,10 @@ void wf_compact_hits(hipStream_t s, const RenderParams& rp, const DevScene& sc, 
 // `count_ptr` (device) holds the number of queued paths; `max_count` bounds it and sizes the grid.
 void wf_surface(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, const uint32_t* count_ptr,
                 uint32_t max_count, uint32_t npix_pad, uint32_t sample_begin, uint32_t* segctr, uint32_t* next_count,
-                uint32_t* gather_queue, uint32_t* gather_count, uint32_t* shadow_count) {
+                uint32_t* gather_queue, uint32_t* gather_count, uint32_t* shadow_count, bool first_bounce) {
     if (max_count == 0) return;
     const dim3 g(blocks_for(max_count, SURF_BLOCK)), b(SURF_BLOCK);
-#define PT_SURFACE(I) hipLaunchKernelGGL(k_surface<I>, g, b, 0, s, rp, sc, ps, queue, count_ptr, npix_pad, sample_begin, segctr, next_count, gather_queue, gather_count, shadow_count)
+#define PT_SURFACE(I) hipLaunchKernelGGL(k_surface<I>, g, b, 0, s, rp, sc, ps, queue, count_ptr, npix_pad, sample_begin, segctr, next_count, gather_queue, gather_count, shadow_count, first_bounce ? 1u : 0u)
     switch (rp.integrator) {
         case INT_RAYTRACER: PT_SURFACE(INT_RAYTRACER); break;
         case INT_ANALYTICDIRECT: PT_SURFACE(INT_ANALYTICDIRECT); break;
