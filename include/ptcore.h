@@ -174,7 +174,13 @@ enum {
      * materials) the hits of a bounce are grouped by class before the surface kernel runs,
      * so that the lanes of a wave take the same branches; 0 = plain path order. Results do
      * not depend on it. */
-    PTC_OPT_GROUP_HITS = 11
+    PTC_OPT_GROUP_HITS = 11,
+    /* 1 (default) = the kernel that adds a bounce's light terms to the path radiance runs
+     * on a second stream of the context, beside the next bounce's extension traversal
+     * (one is bound by HBM, the other by the vector memory pipeline); the context's stream
+     * waits for it before the results are used, so callers see ordinary stream order.
+     * 0 = everything on the one stream. Results do not depend on it. */
+    PTC_OPT_OVERLAP_GATHER = 12
 };
 
 /* ----------------------------------------------------------- entry points -- */

@@ -89,6 +89,7 @@ OPT_BATCH_PATHS, OPT_PROFILE, OPT_COUNT_TRAVERSAL, OPT_BRUTE_FORCE = 5, 6, 7, 8
 OPT_TUNE_TRAVERSAL = 9
 OPT_BVH_BUILDER = 10
 OPT_GROUP_HITS = 11
+OPT_OVERLAP_GATHER = 12
 
 ERR_INVALID, ERR_INTEGRATOR, ERR_DEVICE, ERR_UNSUPPORTED, ERR_NOT_BUILT = -1, -2, -3, -4, -5
 

@@ -28,6 +28,9 @@ struct ptc_context {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
+    hipStream_t aux_stream = nullptr;           // k_gather of a bounce runs here, beside the next bounce's extension traversal
+    hipEvent_t ev_shadow = nullptr, ev_gather = nullptr;
+    bool overlap_gather = true;
     std::string error;
 
     // scene (host copies of what was uploaded)
@@ -216,16 +219,17 @@ struct Timed {  // brackets a launch with events when profiling is on
     ptc_context* c;
     int kind;
     hipEvent_t a = nullptr, b = nullptr;
-    Timed(ptc_context* c_, int kind_) : c(c_), kind(kind_) {
+    hipStream_t s;
+    Timed(ptc_context* c_, int kind_, hipStream_t s_ = nullptr) : c(c_), kind(kind_), s(s_ ? s_ : c_->stream) {
         if (c->profile) {
             a = takeEvent(c);
             b = takeEvent(c);
-            if (a) (void)hipEventRecord(a, c->stream);
+            if (a) (void)hipEventRecord(a, s);
         }
     }
     ~Timed() {
         if (a && b) {
-            (void)hipEventRecord(b, c->stream);
+            (void)hipEventRecord(b, s);
             c->spans.push_back({kind, a, b});
         }
     }
@@ -326,6 +330,9 @@ int runBounces(ptc_context* ctx, const RenderParams& rp, const DevScene& sc, uin
     uint32_t count = count0;
     uint32_t bounce = 0;
     const uint32_t S = rp.samples_per_path;
+    // k_gather only adds to L; hit compaction does too when there is a background colour
+    const bool overlap = ctx->overlap_gather && !(rp.bg[0] != 0.f || rp.bg[1] != 0.f || rp.bg[2] != 0.f);
+    bool gather_pending = false;
     while (count > 0) {
         uint32_t* grp = ctx->qcount + 8 * (bounce & 1u);  // {hit count, next count, shadow-ray count, extend work, shadow work, gather count}
         CHK(hipMemsetAsync(grp, 0, 6 * sizeof(uint32_t), ctx->stream));
@@ -339,6 +346,10 @@ int runBounces(ptc_context* ctx, const RenderParams& rp, const DevScene& sc, uin
             Timed t(ctx, 3);
             wf_compact_hits(ctx->stream, rp, sc, ctx->ps, count, ctx->hitq, grp);
         }
+        if (gather_pending) {  // the last bounce's gather reads what this surface kernel overwrites
+            CHK(hipStreamWaitEvent(ctx->stream, ctx->ev_gather, 0));
+            gather_pending = false;
+        }
         {
             Timed t(ctx, 2);
             wf_surface(ctx->stream, rp, sc, ctx->ps, ctx->hitq, grp, count, ctx->npix_pad, sample_begin, ctx->segctr, grp + 1, ctx->gatherq,
@@ -349,8 +360,19 @@ int runBounces(ptc_context* ctx, const RenderParams& rp, const DevScene& sc, uin
                 Timed t(ctx, 1);
                 wf_shadow(ctx->stream, rp, sc, ctx->ps, grp + 2, (uint64_t)count * S, grp + 4, ctx->resident_waves, ctx->count_trav != 0, ctx->counters, ctx->counters + 4);
             }
-            Timed t(ctx, 2);
-            wf_gather(ctx->stream, rp, sc, ctx->ps, ctx->gatherq, grp + 5, count);
+            if (overlap) {
+                CHK(hipEventRecord(ctx->ev_shadow, ctx->stream));
+                CHK(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_shadow, 0));
+                {
+                    Timed t(ctx, 2, ctx->aux_stream);
+                    wf_gather(ctx->aux_stream, rp, sc, ctx->ps, ctx->gatherq, grp + 5, count);
+                }
+                CHK(hipEventRecord(ctx->ev_gather, ctx->aux_stream));
+                gather_pending = true;
+            } else {
+                Timed t(ctx, 2);
+                wf_gather(ctx->stream, rp, sc, ctx->ps, ctx->gatherq, grp + 5, count);
+            }
             ctx->stats.connect_launches++;
         }
         ctx->stats.shade_launches++;
@@ -365,6 +387,7 @@ int runBounces(ptc_context* ctx, const RenderParams& rp, const DevScene& sc, uin
         std::swap(ctx->ps.pid, ctx->ps.pid_next);
         ++bounce;
     }
+    if (gather_pending) CHK(hipStreamWaitEvent(ctx->stream, ctx->ev_gather, 0));
     return PTC_OK;
 }
 
@@ -485,6 +508,9 @@ int ptc_create(int device_ordinal, ptc_context** out) {
     };
     if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     ctx->stream = ctx->own_stream;
+    if ((e = hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    if ((e = hipEventCreateWithFlags(&ctx->ev_shadow, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreateWithFlags(&ctx->ev_gather, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipMalloc((void**)&ctx->qcount, N_QCOUNT * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void**)&ctx->counters, N_COUNTERS * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMemset(ctx->counters, 0, N_COUNTERS * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
@@ -507,6 +533,9 @@ int ptc_destroy(ptc_context* ctx) {
     if (ctx->h_count) (void)hipHostFree(ctx->h_count);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
+    if (ctx->ev_shadow) (void)hipEventDestroy(ctx->ev_shadow);
+    if (ctx->ev_gather) (void)hipEventDestroy(ctx->ev_gather);
     delete ctx;
     return PTC_OK;
 }
@@ -770,6 +799,7 @@ int ptc_set_option(ptc_context* ctx, int option, int64_t value) {
         case PTC_OPT_COUNT_TRAVERSAL: ctx->count_trav = value != 0; break;
         case PTC_OPT_BRUTE_FORCE: ctx->brute_force = value != 0; break;
         case PTC_OPT_GROUP_HITS: ctx->group_hits = value != 0; break;
+        case PTC_OPT_OVERLAP_GATHER: ctx->overlap_gather = value != 0; break;
         case PTC_OPT_BVH_BUILDER:
             if (value != 0 && value != 1) return fail(ctx, PTC_ERR_INVALID, "BVH builder must be 0 (LBVH) or 1 (PLOC)");
             ctx->bvh_builder = (int)value;

@@ -1392,10 +1392,13 @@ __global__ __launch_bounds__(SURF_BLOCK) void k_surface(RenderParams rp, DevScen
 }
 
 // After k_shadow: the radiance of the segments that sampled the lights.
+#ifndef GATHER_BLOCK
+#define GATHER_BLOCK 256   /* small blocks: they run in the wave slots the traversal kernel of the next bounce leaves free */
+#endif
 template <int INTEG>
-__global__ __launch_bounds__(GEN_BLOCK) void k_gather(RenderParams rp, DevScene sc, PathState ps, const uint32_t* __restrict__ gather_queue,
+__global__ __launch_bounds__(GATHER_BLOCK) void k_gather(RenderParams rp, DevScene sc, PathState ps, const uint32_t* __restrict__ gather_queue,
                                                       const uint32_t* __restrict__ gather_count) {
-    const uint32_t i = blockIdx.x * GEN_BLOCK + threadIdx.x;
+    const uint32_t i = blockIdx.x * GATHER_BLOCK + threadIdx.x;
     if (i >= *gather_count) return;
     const uint32_t seg = gather_queue[i];  // position in the hit queue
     const float4 a4 = ps.g_a[seg], t4 = ps.g_thr[seg];
@@ -1615,7 +1618,7 @@ void wf_surface(hipStream_t s, const RenderParams& rp, const DevScene& sc, const
 void wf_gather(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* gather_queue, const uint32_t* gather_count,
                uint32_t max_count) {
     if (max_count == 0) return;
-    const dim3 g(blocks_for(max_count, GEN_BLOCK)), b(GEN_BLOCK);
+    const dim3 g(blocks_for(max_count, GATHER_BLOCK)), b(GATHER_BLOCK);
     switch (rp.integrator) {
         case INT_RAYTRACER: hipLaunchKernelGGL(k_gather<INT_RAYTRACER>, g, b, 0, s, rp, sc, ps, gather_queue, gather_count); break;
         case INT_DIRECT: hipLaunchKernelGGL(k_gather<INT_DIRECT>, g, b, 0, s, rp, sc, ps, gather_queue, gather_count); break;

@@ -289,6 +289,26 @@ def test_hit_grouping_does_not_change_results(rel, over):
     assert np.array_equal(out[0].view(np.uint32), out[1].view(np.uint32))
 
 
+@pytest.mark.parametrize("rel,over", [("scene4/dragon.test", dict(size="320 240", spp="8")), ("scene3/cornellRR.test", dict(size="96 96", spp="16")),
+                                      ("scene2/sphere.test", dict(size="160 120"))])
+def test_gather_on_second_stream_does_not_change_results(rel, over):
+    """The radiance gather of a bounce beside the next bounce's traversal (second stream, two
+    events per bounce) or everything on one stream: bit-identical sums, also when the same
+    context renders several frames in a row."""
+    scene = load(rel, **over)
+    out = []
+    for overlap in (0, 1):
+        r = Renderer(scene, options={_ffi.OPT_SEMANTICS: 1, _ffi.OPT_SEEDING: 1, _ffi.OPT_BOUNCE_CAP: 8, _ffi.OPT_OVERLAP_GATHER: overlap})
+        frames = []
+        for _ in range(3):
+            r.render_range(0, scene.samples_per_pixel, clear=True)
+            frames.append(r.sums().copy())
+        r.close()
+        assert np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32)) and np.array_equal(frames[0].view(np.uint32), frames[2].view(np.uint32))
+        out.append(frames[0])
+    assert np.array_equal(out[0].view(np.uint32), out[1].view(np.uint32))
+
+
 @pytest.mark.parametrize("kind,semantics", [("direct", 0), ("nee", 0), ("nee", 1), ("raytracer", 0)])
 def test_other_dragon_scenes(kind, semantics):
     """scene 2/dragon.test (direct, 50 stratified shadow rays per path), scene 3/dragon.test
