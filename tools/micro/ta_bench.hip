@@ -38,6 +38,47 @@ __global__ __launch_bounds__(256) void k_chase(const uint4* __restrict__ rec, ui
     if (acc == 0x12345678u) out[0] = acc;
 }
 
+// The same chase with every load issued twice, once for each half of the wave (exec-masked): does a
+// load with 32 distinct lines cost less than half of one with 64?
+template <int PARTS>
+__global__ __launch_bounds__(256) void k_chase_split(const uint4* __restrict__ rec, uint32_t mask, int steps, int groups, uint32_t* __restrict__ out) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t idx = (blockIdx.x * 256u + threadIdx.x) * 2654435761u;
+    uint32_t acc = 0;
+    const uint32_t per = 64u / (uint32_t)groups;
+    for (int s = 0; s < steps; ++s) {
+        const uint4* p = rec + (size_t)(idx & mask) * 4;
+        uint32_t v = 0;
+        for (int g = 0; g < groups; ++g) {
+            if (lane / per == (uint32_t)g) {
+#pragma unroll
+                for (int k = 0; k < PARTS; ++k) { const uint4 q = p[k]; v += q.x ^ q.y ^ q.z ^ q.w; }
+            }
+            asm volatile("" ::: "memory");
+        }
+        acc += v;
+        idx = idx * 1664525u + 1013904223u + (v & 1u);
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
+template <int PARTS>
+static void run_split(const uint4* d_rec, uint32_t n_rec, int groups, int blocks_per_cu, uint32_t* d_out, int cus) {
+    const int steps = 2000, blocks = cus * blocks_per_cu;
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    hipLaunchKernelGGL((k_chase_split<PARTS>), dim3(blocks), dim3(256), 0, 0, d_rec, n_rec - 1, 200, groups, d_out);
+    CHECK(hipEventRecord(a));
+    hipLaunchKernelGGL((k_chase_split<PARTS>), dim3(blocks), dim3(256), 0, 0, d_rec, n_rec - 1, steps, groups, d_out);
+    CHECK(hipEventRecord(b));
+    CHECK(hipEventSynchronize(b));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, a, b));
+    const double wave_steps = (double)blocks * 4 * steps;
+    printf("%d x dwordx4 in %d lane groups, %2d waves per CU, records %8u: %7.3f ms, %7.2f ns per wave step per CU (%6.3f ns per lane record)\n", PARTS, groups,
+           blocks_per_cu * 4, n_rec, ms, ms * 1e6 / (wave_steps / cus), ms * 1e6 / (wave_steps / cus) / 64.0);
+}
+
 template <int PARTS, int WIDTH>
 static void run(const char* name, const uint4* d_rec, uint32_t n_rec, int lanes, uint32_t* d_out, int cus) {
     const int steps = 2000, blocks = cus * 6;  // 24 waves per CU
@@ -76,6 +117,15 @@ int main() {
             run<4, 4>("4 x dwordx4 (one node)", d_rec, n_rec, lanes, d_out, cus);
             run<4, 2>("4 x dwordx2", d_rec, n_rec, lanes, d_out, cus);
             run<4, 1>("4 x dword", d_rec, n_rec, lanes, d_out, cus);
+        }
+    }
+    printf("\nall 64 lanes, the load split over lane groups / fewer waves per CU\n");
+    for (uint32_t n_rec : {1u << 15, 1u << 17}) {
+        for (int bpc : {6, 3, 2}) {
+            for (int groups : {1, 2, 4}) {
+                run_split<1>(d_rec, n_rec, groups, bpc, d_out, cus);
+                run_split<4>(d_rec, n_rec, groups, bpc, d_out, cus);
+            }
         }
     }
     return 0;
