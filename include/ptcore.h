@@ -240,6 +240,17 @@ int  ptc_bind_sum_buffer(ptc_context* ctx, void* device_ptr, size_t bytes);
 int  ptc_set_stream(ptc_context* ctx, void* hip_stream);
 int  ptc_synchronize(ptc_context* ctx);
 
+/* Build-only, needs no device: the host step of ptc_build that turns a finished hierarchy of
+ * 64-byte two-child nodes (node 0 = root; per node lo0[3] hi0[3] lo1[3] hi1[3] as floats, then the
+ * two child words and 8 bytes of padding; child word = kind << 30 | (count-1) << 27 | index with
+ * kind 0 node, 1 triangle leaf, 2 sphere leaf, 3 empty) into 64-byte four-wide nodes with 8-bit child
+ * boxes (origin[3], scale[3] as floats, then qlo.x[4] qlo.y[4] qlo.z[4] qhi.x[4] qhi.y[4] qhi.z[4]
+ * as bytes, then four child words).  PTC_ERR_UNSUPPORTED = the hierarchy cannot be represented that
+ * way (a box that is not finite, too deep): ptc_build then keeps the two-child form only.
+ * Exposed so that the rounding of the child boxes can be checked without a GPU. */
+int  ptc_collapse_wide(const void* binary_nodes, uint32_t n_nodes, void* wide_nodes_out, uint32_t capacity,
+                       uint32_t* n_wide_out, uint32_t* depth_out);
+
 int  ptc_set_option(ptc_context* ctx, int option, int64_t value);
 int  ptc_get_stats(ptc_context* ctx, PtcStats* out);
 int  ptc_reset_stats(ptc_context* ctx);

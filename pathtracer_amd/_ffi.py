@@ -123,6 +123,7 @@ CORE_SYMBOLS = [
     "ptc_set_triangles", "ptc_set_spheres", "ptc_set_lights", "ptc_set_background", "ptc_build", "ptc_render",
     "ptc_render_range", "ptc_resolve", "ptc_primary_hits", "ptc_read_result", "ptc_read_sum",
     "ptc_bind_sum_buffer", "ptc_set_stream", "ptc_synchronize", "ptc_set_option", "ptc_get_stats", "ptc_reset_stats",
+    "ptc_collapse_wide",
 ]
 
 

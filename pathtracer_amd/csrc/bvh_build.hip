@@ -742,6 +742,7 @@ bool collapseWide(const std::vector<BvhNode>& bin, std::vector<WideNode>& wide, 
                 uint8_t* qhi[3] = {out.qhi_x, out.qhi_y, out.qhi_z};
                 for (int k = 0; k < 3; ++k) {
                     const double o = (double)u.lo[k], sc = (double)scale[k];
+                    if (!std::isfinite(ch[c].box.lo[k]) || !std::isfinite(ch[c].box.hi[k])) return false;
                     double lo = std::floor(((double)ch[c].box.lo[k] - o) / sc), hi = std::ceil(((double)ch[c].box.hi[k] - o) / sc);
                     lo = std::min(std::max(lo, 0.0), 255.0);
                     hi = std::min(std::max(hi, 0.0), 255.0);
@@ -896,6 +897,18 @@ std::string bvh_build(hipStream_t s, const BvhBuildInput& in, BvhBuildOutput& ou
         }
     }
     return "";
+}
+
+int bvh_collapse_wide_host(const BvhNode* bin, uint32_t n_nodes, WideNode* out, uint32_t capacity, uint32_t* n_wide, uint32_t* depth) {
+    std::vector<BvhNode> b(bin, bin + n_nodes);
+    std::vector<WideNode> w;
+    uint32_t d = 0;
+    if (!collapseWide(b, w, d)) return 1;
+    if (w.size() > capacity) return 2;
+    std::memcpy(out, w.data(), w.size() * sizeof(WideNode));
+    *n_wide = (uint32_t)w.size();
+    *depth = d;
+    return 0;
 }
 
 void bvh_free(BvhBuildOutput& o) {

@@ -816,6 +816,12 @@ int ptc_set_option(ptc_context* ctx, int option, int64_t value) {
     return PTC_OK;
 }
 
+int ptc_collapse_wide(const void* binary_nodes, uint32_t n_nodes, void* wide_nodes_out, uint32_t capacity, uint32_t* n_wide_out, uint32_t* depth_out) {
+    if (!binary_nodes || !wide_nodes_out || !n_wide_out || !depth_out || n_nodes == 0) return PTC_ERR_INVALID;
+    const int rc = bvh_collapse_wide_host((const BvhNode*)binary_nodes, n_nodes, (WideNode*)wide_nodes_out, capacity, n_wide_out, depth_out);
+    return rc == 0 ? PTC_OK : rc == 1 ? PTC_ERR_UNSUPPORTED : PTC_ERR_INVALID;
+}
+
 int ptc_get_stats(ptc_context* ctx, PtcStats* out) {
     ENTER();
     if (!out) return fail(ctx, PTC_ERR_INVALID, "null output");
