@@ -1241,19 +1241,21 @@ __device__ __forceinline__ vec3 gather_radiance(const RenderParams& rp, const De
     return a;
 }
 
-#ifndef SURF_BLOCK
-#define SURF_BLOCK 256   /* measured: 256 > 512 (+1-3 %) > 1024 (-4 %) >> 128 (-9..-20 %: one queue atomic per block) */
-#endif
+// Threads per block of k_surface.  With one or two light samples per hit: 256 (measured 256 > 512 by
+// 1-3 % > 1024 by 4 % more >> 128).  With many samples per hit every sample takes one queue atomic
+// per block, and the rate of atomics on one word (about 88 per microsecond) bounds the kernel: 1024.
+#define SURF_BLOCK_FEW 256
+#define SURF_BLOCK_MANY 1024
 // One thread per path of the bounce that hit something.
 template <int INTEG>
-__global__ __launch_bounds__(SURF_BLOCK) void k_surface(RenderParams rp, DevScene sc, PathState ps, const uint32_t* __restrict__ queue,
+__global__ __launch_bounds__(SURF_BLOCK_MANY, 5) void k_surface(RenderParams rp, DevScene sc, PathState ps, const uint32_t* __restrict__ queue,
                                                        const uint32_t* __restrict__ count_ptr, uint32_t npix_pad, uint32_t sample_begin, uint32_t* __restrict__ segctr,
                                                        uint32_t* __restrict__ next_count,
                                                        uint32_t* __restrict__ gather_queue, uint32_t* __restrict__ gather_count,
                                                        uint32_t* __restrict__ shadow_count, uint32_t first_bounce) {
     const uint32_t count = *count_ptr;  // hits of this bounce, written by k_compact_hits
-    if (blockIdx.x * SURF_BLOCK >= count) return;
-    const uint32_t i = blockIdx.x * SURF_BLOCK + threadIdx.x;
+    if (blockIdx.x * blockDim.x >= count) return;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool hit = i < count;
     bool sample = false, alive = false, gather = false;
     uint32_t p = 0, bounce = 0;
@@ -1601,7 +1603,8 @@ void wf_surface(hipStream_t s, const RenderParams& rp, const DevScene& sc, const
                 uint32_t max_count, uint32_t npix_pad, uint32_t sample_begin, uint32_t* segctr, uint32_t* next_count,
                 uint32_t* gather_queue, uint32_t* gather_count, uint32_t* shadow_count, bool first_bounce) {
     if (max_count == 0) return;
-    const dim3 g(blocks_for(max_count, SURF_BLOCK)), b(SURF_BLOCK);
+    const uint32_t block = rp.samples_per_path <= 2u ? SURF_BLOCK_FEW : SURF_BLOCK_MANY;
+    const dim3 g(blocks_for(max_count, block)), b(block);
 #define PT_SURFACE(I) hipLaunchKernelGGL(k_surface<I>, g, b, 0, s, rp, sc, ps, queue, count_ptr, npix_pad, sample_begin, segctr, next_count, gather_queue, gather_count, shadow_count, first_bounce ? 1u : 0u)
     switch (rp.integrator) {
         case INT_RAYTRACER: PT_SURFACE(INT_RAYTRACER); break;
