@@ -1305,23 +1305,38 @@ __global__ __launch_bounds__(SURF_BLOCK_MANY, 5) void k_surface(RenderParams rp,
                 }
             }
         } else {
-            for (uint32_t q = 0; q < rp.samples_per_path; ++q) {
-                vec3 sh_o = mk3(0.f), sh_d = mk3(0.f);
-                float sh_tmax = 0.f;
-                bool need_ray = false;
-                uint32_t slot = 0;
-                if (sample) {
-                    const vec3 term = light_sample<INTEG>(rp, sc, at, material_of(sc, at.mat), sg.seed, q, sh_o, sh_d, sh_tmax);
-                    need_ray = !(term.x == 0.f && term.y == 0.f && term.z == 0.f);
-                    slot = contrib_slot(ps, i, q);
-                    ps.contrib[slot] = term.x;
-                    ps.contrib[slot + plane] = term.y;
-                    ps.contrib[slot + 2 * plane] = term.z;
+            // MANY_STEP samples per queue reservation: one atomic and one round of barriers for all of them
+            // (four for the integrators that are used with dozens of light samples, two where the
+            // registers of the rays in flight would spill)
+            constexpr uint32_t MANY_STEP = (INTEG == INT_DIRECT || INTEG == INT_RAYTRACER) ? 4u : 2u;
+            for (uint32_t q0 = 0; q0 < rp.samples_per_path; q0 += MANY_STEP) {
+                vec3 sh_o[MANY_STEP], sh_d[MANY_STEP];
+                float sh_tmax[MANY_STEP];
+                bool need_ray[MANY_STEP];
+                uint32_t slot[MANY_STEP], at_[MANY_STEP];
+#pragma unroll
+                for (uint32_t k = 0; k < MANY_STEP; ++k) {
+                    const uint32_t q = q0 + k;
+                    sh_o[k] = sh_d[k] = mk3(0.f);
+                    sh_tmax[k] = 0.f;
+                    need_ray[k] = false;
+                    slot[k] = 0;
+                    if (sample && q < rp.samples_per_path) {
+                        const vec3 term = light_sample<INTEG>(rp, sc, at, material_of(sc, at.mat), sg.seed, q, sh_o[k], sh_d[k], sh_tmax[k]);
+                        need_ray[k] = !(term.x == 0.f && term.y == 0.f && term.z == 0.f);
+                        slot[k] = contrib_slot(ps, i, q);
+                        ps.contrib[slot[k]] = term.x;
+                        ps.contrib[slot[k] + plane] = term.y;
+                        ps.contrib[slot[k] + 2 * plane] = term.z;
+                    }
                 }
-                const uint32_t at_ = queue_reserve(need_ray, shadow_count);
-                if (need_ray) {
-                    ps.sh_o[at_] = make_float4(sh_o.x, sh_o.y, sh_o.z, sh_tmax);
-                    ps.sh_d[at_] = make_float4(sh_d.x, sh_d.y, sh_d.z, u2f(slot));
+                queue_reserve_streams<MANY_STEP>(need_ray, shadow_count, at_);
+#pragma unroll
+                for (uint32_t k = 0; k < MANY_STEP; ++k) {
+                    if (need_ray[k]) {
+                        ps.sh_o[at_[k]] = make_float4(sh_o[k].x, sh_o[k].y, sh_o[k].z, sh_tmax[k]);
+                        ps.sh_d[at_[k]] = make_float4(sh_d[k].x, sh_d[k].y, sh_d[k].z, u2f(slot[k]));
+                    }
                 }
             }
         }
