@@ -17,7 +17,7 @@ def main():
     for t in trace:
         for r in csv.DictReader(open(t)):
             res.setdefault(r["Kernel_Name"], (r["VGPR_Count"], r["Accum_VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"], r["Scratch_Size"]))
-    lines = [f"# {title}", "", "| kernel | calls | total ms | avg us | % | vgpr | sgpr | lds B | scratch B |", "|---|---|---|---|---|---|---|---|---|"]
+    lines = [f"# {title}", "", "(vgpr as rocprofv3 reports it on gfx950: half of the compiler's NumVgprs, e.g. 40 for the 80 registers of k_trace_deferred)", "", "| kernel | calls | total ms | avg us | % | vgpr | sgpr | lds B | scratch B |", "|---|---|---|---|---|---|---|---|---|"]
     for s in stats:
         for r in csv.DictReader(open(s)):
             name = r["Name"]
