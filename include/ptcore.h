@@ -110,6 +110,8 @@ typedef struct PtcStats {
     uint64_t shadow_nodes_visited, shadow_prims_tested; /* shadow rays, same option                          */
     uint32_t bvh_nodes, bvh_max_depth;
     double   build_ms;
+    uint64_t path_state_bytes; /* device memory of the per-path arrays of a batch    */
+    uint64_t batch_paths;      /* camera paths of the largest batch rendered so far  */
 } PtcStats;
 
 typedef struct ptc_context ptc_context;
@@ -143,7 +145,10 @@ enum {
      * the reference would iterate literally. Default 1024. */
     PTC_OPT_BOUNCE_CAP = 3,
     /* 1 = stop a path once its throughput is exactly (0,0,0) (every later
-     * contribution is radiance*throughput, RayTracer.cu:918). Default 1. */
+     * contribution is radiance*throughput, RayTracer.cu:918). Default 1. Takes
+     * effect with counter seeding only: under reference seeding the segments of a
+     * dead path still advance the pixel's seed counter (PinholeCamera.cu:56) and
+     * with it the seeds of every later sample, so they are traced. */
     PTC_OPT_CULL_ZERO = 4,
     /* Maximum camera paths in flight per wavefront batch (rounded to whole samples over
      * the image, and limited to what fits in half of the free device memory at about
@@ -217,8 +222,12 @@ int  ptc_build(ptc_context* ctx);
  * (PinholeCamera.cu:70-80). */
 int  ptc_render(ptc_context* ctx, int frame_id, uint32_t width, uint32_t height);
 /* Build-only: accumulate samples [spp_begin, spp_end) into the pre-gamma sum
- * buffer (cleared first when clear != 0) without resolving; asynchronous on the
- * context's stream. Used for the samples-per-pixel split across GPUs. */
+ * buffer (cleared first when clear != 0) without resolving. Used for the
+ * samples-per-pixel split across GPUs. The work is issued on the context's
+ * stream, but the call is NOT asynchronous: the host waits for the stream once
+ * per bounce (the number of surviving paths sizes the next launches), so it
+ * returns with all but the last few kernels done; the sums are complete after
+ * ptc_synchronize (or any later operation on the same stream). */
 int  ptc_render_range(ptc_context* ctx, int frame_id, uint32_t width, uint32_t height,
                       int32_t spp_begin, int32_t spp_end, int clear);
 /* Build-only: result = pow(sum / total_spp, 1/gamma) (frame 1) or the frame

@@ -1173,7 +1173,10 @@ F3 generateRays(const Ctx& c, uint32_t x, uint32_t y, int j0, int j1) {
             origin = payload.origin;
             dir = payload.dir;
             ++b;
-            if (o.cull_zero && payload.throughput.x == 0.f && payload.throughput.y == 0.f && payload.throughput.z == 0.f) break;
+            // Result-preserving cull, counter seeding only: under reference seeding every segment the
+            // reference traces advances `i` (:56), which seeds all later samples of the pixel, and how
+            // many segments a dead path still has is not knowable without tracing them.
+            if (o.cull_zero && o.seeding == 1 && payload.throughput.x == 0.f && payload.throughput.y == 0.f && payload.throughput.z == 0.f) break;
         } while (!payload.done && payload.depth != w.maxDepthEff && b < o.bounce_cap);  // :66
         if (counted) {
             c.cnt->paths++;

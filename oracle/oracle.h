@@ -47,7 +47,7 @@ typedef struct OrcOptions {
     int32_t  semantics;   /* 0 literal, 1 intended (see PTC_OPT_SEMANTICS)        */
     int32_t  seeding;     /* 0 reference, 1 counter (see PTC_OPT_SEEDING)         */
     uint32_t bounce_cap;  /* hard limit on segments per path                      */
-    int32_t  cull_zero;   /* stop a path whose throughput is exactly 0            */
+    int32_t  cull_zero;   /* stop a path whose throughput is exactly 0 (counter seeding only) */
     int32_t  use_bvh;     /* 0 brute force over all primitives, 1 CPU SAH BVH     */
     int32_t  threads;     /* worker threads over pixel rows, <=0: 1               */
     int32_t  frame_id;    /* frameID, 1 for a single-frame render                 */

@@ -64,7 +64,8 @@ class Stats(C.Structure):
                 ("extend_ms", C.c_double), ("connect_ms", C.c_double), ("shade_ms", C.c_double), ("other_ms", C.c_double),
                 ("nodes_visited", C.c_uint64), ("prims_tested", C.c_uint64),
                 ("shadow_nodes_visited", C.c_uint64), ("shadow_prims_tested", C.c_uint64),
-                ("bvh_nodes", C.c_uint32), ("bvh_max_depth", C.c_uint32), ("build_ms", C.c_double)]
+                ("bvh_nodes", C.c_uint32), ("bvh_max_depth", C.c_uint32), ("build_ms", C.c_double),
+                ("path_state_bytes", C.c_uint64), ("batch_paths", C.c_uint64)]
 
 
 class SceneView(C.Structure):

@@ -900,6 +900,24 @@ std::string bvh_build(hipStream_t s, const BvhBuildInput& in, BvhBuildOutput& ou
 }
 
 int bvh_collapse_wide_host(const BvhNode* bin, uint32_t n_nodes, WideNode* out, uint32_t capacity, uint32_t* n_wide, uint32_t* depth) {
+    // caller-supplied nodes: every internal child must exist and be reached once (a tree, no cycles)
+    {
+        std::vector<uint8_t> seen(n_nodes, 0);
+        std::vector<uint32_t> todo(1, 0u);
+        seen[0] = 1;
+        while (!todo.empty()) {
+            const uint32_t b = todo.back();
+            todo.pop_back();
+            for (int c = 0; c < 2; ++c) {
+                const uint32_t ref = bin[b].child[c];
+                if (REF_KIND(ref) != REF_INTERNAL) continue;
+                const uint32_t k = REF_NODE(ref);
+                if (k >= n_nodes || seen[k]) return 3;
+                seen[k] = 1;
+                todo.push_back(k);
+            }
+        }
+    }
     std::vector<BvhNode> b(bin, bin + n_nodes);
     std::vector<WideNode> w;
     uint32_t d = 0;

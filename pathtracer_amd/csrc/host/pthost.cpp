@@ -1,6 +1,7 @@
 // pthost.cpp -- C wrappers over SceneLoader and the PNG writer.
 #include "pthost.h"
 
+#include <memory>
 #include <sstream>
 #include <string>
 
@@ -23,9 +24,9 @@ int pth_scene_load(const char* filename, pth_scene** out) {
     if (!filename || !out) { g_error = "null argument"; return -1; }
     try {
         SceneLoader loader;
-        auto* h = new pth_scene;
+        std::unique_ptr<pth_scene> h(new pth_scene);
         h->scene = loader.load(filename);
-        *out = h;
+        *out = h.release();
         return 0;
     } catch (const std::exception& e) {
         g_error = e.what();
@@ -38,9 +39,9 @@ int pth_scene_load_text(const char* text, pth_scene** out) {
     try {
         SceneLoader loader;
         std::istringstream in(text);
-        auto* h = new pth_scene;
+        std::unique_ptr<pth_scene> h(new pth_scene);
         h->scene = loader.loadStream(in);
-        *out = h;
+        *out = h.release();
         return 0;
     } catch (const std::exception& e) {
         g_error = e.what();

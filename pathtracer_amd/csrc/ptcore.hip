@@ -30,6 +30,7 @@ struct ptc_context {
     hipStream_t own_stream = nullptr;
     hipStream_t aux_stream = nullptr;           // k_gather of a bounce runs here, beside the next bounce's extension traversal
     hipEvent_t ev_shadow = nullptr, ev_gather = nullptr;
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;  // build timing
     bool overlap_gather = true;
     std::string error;
 
@@ -58,7 +59,6 @@ struct ptc_context {
     PtcQuadLight* d_qlights = nullptr;
     BvhBuildOutput bvh;
     bool built = false;
-    bool lights_dirty = true;
 
     // render targets
     uint32_t width = 0, height = 0, npix_pad = 0;
@@ -72,8 +72,12 @@ struct ptc_context {
     int32_t ref_next_sample = 0;  // reference seeding: the sample the per-pixel history is at
     PtcHitRecord* d_hits = nullptr;
 
-    // wavefront state
+    // wavefront state: every per-path array is a slice of one pool (one allocation, or the
+    // library's static scratch array while ptc_render_range_static runs)
     PathState ps{};
+    void* path_pool = nullptr;
+    size_t path_pool_bytes = 0;
+    bool no_alloc = false;                      // inside ptc_render_range_static: nothing may allocate
     uint32_t contrib_samples = 0;
     uint32_t* hitq = nullptr;                   // paths of this bounce that hit something
     uint32_t* gatherq = nullptr;                // segments of this bounce whose radiance waits for the light terms
@@ -133,32 +137,46 @@ void freeTargets(ptc_context* c) {
 }
 
 void freePaths(ptc_context* c) {
-    for (void* p : {(void*)c->ps.o_seed, (void*)c->ps.d_depth, (void*)c->ps.thr, (void*)c->ps.L, (void*)c->ps.g_a, (void*)c->ps.g_thr, (void*)c->ps.hit_t, (void*)c->ps.hit_ref,
-                    (void*)c->ps.contrib, (void*)c->ps.sh_o, (void*)c->ps.sh_d, (void*)c->ps.pid, (void*)c->ps.o_seed_next, (void*)c->ps.d_depth_next,
-                    (void*)c->ps.thr_next, (void*)c->ps.pid_next, (void*)c->hitq, (void*)c->gatherq})
-        if (p) (void)hipFree(p);
+    if (c->path_pool) (void)hipFree(c->path_pool);
+    c->path_pool = nullptr;
+    c->path_pool_bytes = 0;
     c->ps = PathState{};
     c->hitq = c->gatherq = nullptr;
     c->contrib_samples = 0;
 }
 
+// Pixels of the image padded to whole 64x64-pixel blocks of 8x8 tiles (the path numbering's unit).
+uint64_t paddedPixels(uint32_t w, uint32_t h) { return (uint64_t)((w + 63u) / 64u) * ((h + 63u) / 64u) * 4096u; }
+
 int ensureTargets(ptc_context* ctx, uint32_t w, uint32_t h) {
     if (w == 0 || h == 0) return fail(ctx, PTC_ERR_INVALID, "image size must be non-zero");
+    const size_t n = (size_t)w * h;
+    // a caller-owned sum buffer must hold this image, whenever it was bound
+    if (ctx->acc_ext && ctx->acc_ext_bytes < n * 3 * sizeof(float))
+        return fail(ctx, PTC_ERR_INVALID, "the bound sum buffer is too small for this image size");
     if (ctx->width == w && ctx->height == h) {
         ctx->acc = ctx->acc_ext ? (float*)ctx->acc_ext : ctx->acc_own;
         return PTC_OK;
     }
     freeTargets(ctx);
-    const size_t n = (size_t)w * h;
-    const uint32_t tiles = ((w + 63u) / 64u) * ((h + 63u) / 64u) * 64u;  // whole 64x64-pixel blocks of 8x8 tiles
-    CHK(hipMalloc((void**)&ctx->acc_own, n * 3 * sizeof(float)));
-    CHK(hipMalloc((void**)&ctx->result, n * 3 * sizeof(float)));
-    CHK(hipMalloc((void**)&ctx->segctr, (size_t)tiles * 64 * sizeof(uint32_t)));
-    CHK(hipMalloc((void**)&ctx->pixseed, (size_t)tiles * 64 * sizeof(uint32_t)));
-    CHK(hipMalloc((void**)&ctx->d_hits, n * sizeof(PtcHitRecord)));
-    CHK(hipMemsetAsync(ctx->acc_own, 0, n * 3 * sizeof(float), ctx->stream));
-    CHK(hipMemsetAsync(ctx->result, 0, n * 3 * sizeof(float), ctx->stream));
-    CHK(hipMemsetAsync(ctx->segctr, 0, (size_t)tiles * 64 * sizeof(uint32_t), ctx->stream));
+    if (paddedPixels(w, h) > 0xFFFFF000ull) return fail(ctx, PTC_ERR_INVALID, "image too large");
+    const uint32_t tiles = (uint32_t)(paddedPixels(w, h) / 64u);
+    hipError_t e = hipSuccess;
+    auto step = [&](hipError_t r) {
+        if (e == hipSuccess) e = r;
+    };
+    step(hipMalloc((void**)&ctx->acc_own, n * 3 * sizeof(float)));
+    step(hipMalloc((void**)&ctx->result, n * 3 * sizeof(float)));
+    step(hipMalloc((void**)&ctx->segctr, (size_t)tiles * 64 * sizeof(uint32_t)));
+    step(hipMalloc((void**)&ctx->pixseed, (size_t)tiles * 64 * sizeof(uint32_t)));
+    step(hipMalloc((void**)&ctx->d_hits, n * sizeof(PtcHitRecord)));
+    if (e == hipSuccess) step(hipMemsetAsync(ctx->acc_own, 0, n * 3 * sizeof(float), ctx->stream));
+    if (e == hipSuccess) step(hipMemsetAsync(ctx->result, 0, n * 3 * sizeof(float), ctx->stream));
+    if (e == hipSuccess) step(hipMemsetAsync(ctx->segctr, 0, (size_t)tiles * 64 * sizeof(uint32_t), ctx->stream));
+    if (e != hipSuccess) {
+        freeTargets(ctx);  // nothing half allocated stays behind
+        return fail(ctx, PTC_ERR_DEVICE, std::string("allocating the render targets: ") + hipGetErrorString(e));
+    }
     ctx->width = w;
     ctx->height = h;
     ctx->npix_pad = tiles * 64u;
@@ -167,30 +185,54 @@ int ensureTargets(ptc_context* ctx, uint32_t w, uint32_t h) {
     return PTC_OK;
 }
 
+// Slices of one pool for the per-path arrays of a batch of `capacity` paths with `S` light samples per
+// segment; every slice starts on a 256-byte boundary.  base == nullptr: only the size is computed.
+size_t carvePaths(char* base, uint32_t capacity, uint32_t S, PathState& ps, uint32_t*& hitq, uint32_t*& gatherq) {
+    size_t at = 0;
+    auto take = [&](size_t bytes) {
+        char* p = base ? base + at : nullptr;
+        at += (std::max<size_t>(bytes, 1) + 255u) & ~(size_t)255u;
+        return (void*)p;
+    };
+    const size_t n = capacity, ns = (size_t)capacity * S;
+    ps.o_seed = (float4*)take(n * sizeof(float4));
+    ps.d_depth = (float4*)take(n * sizeof(float4));
+    ps.thr = (float4*)take(n * sizeof(float4));
+    ps.L = (float4*)take(n * sizeof(float4));
+    ps.g_a = (float4*)take(n * sizeof(float4));
+    ps.g_thr = (float4*)take(n * sizeof(float4));
+    ps.hit_t = (float*)take(n * sizeof(float));
+    ps.hit_ref = (int32_t*)take(n * sizeof(int32_t));
+    ps.contrib = (float*)take(ns * 3 * sizeof(float));
+    ps.sh_o = (float4*)take(ns * sizeof(float4));
+    ps.sh_d = (float4*)take(ns * sizeof(float4));
+    ps.pid = (uint32_t*)take(n * sizeof(uint32_t));
+    ps.o_seed_next = (float4*)take(n * sizeof(float4));
+    ps.d_depth_next = (float4*)take(n * sizeof(float4));
+    ps.thr_next = (float4*)take(n * sizeof(float4));
+    ps.pid_next = (uint32_t*)take(n * sizeof(uint32_t));
+    hitq = (uint32_t*)take(n * sizeof(uint32_t));
+    gatherq = (uint32_t*)take(n * sizeof(uint32_t));
+    ps.capacity = capacity;
+    return at;
+}
+
+// Device memory one path of a batch takes (see carvePaths): the packed state twice, L, hit, gather
+// record, two queue entries, and per light sample its term and its shadow-ray record.
+uint64_t bytesPerPath(uint32_t S) { return 2u * (48u + 4u) + 16u + 8u + 32u + 8u + (uint64_t)S * (12u + 32u); }
+
 int ensurePaths(ptc_context* ctx, uint32_t capacity, uint32_t contrib_samples) {
     if (ctx->ps.capacity >= capacity && ctx->contrib_samples >= contrib_samples) return PTC_OK;
+    if (ctx->no_alloc) return fail(ctx, PTC_ERR_INVALID, "the path arrays would have to grow inside a call that may not allocate");
     capacity = std::max(capacity, ctx->ps.capacity);
     contrib_samples = std::max(contrib_samples, ctx->contrib_samples);
     freePaths(ctx);
-    CHK(hipMalloc((void**)&ctx->ps.o_seed, (size_t)capacity * sizeof(float4)));
-    CHK(hipMalloc((void**)&ctx->ps.d_depth, (size_t)capacity * sizeof(float4)));
-    CHK(hipMalloc((void**)&ctx->ps.thr, (size_t)capacity * sizeof(float4)));
-    CHK(hipMalloc((void**)&ctx->ps.L, (size_t)capacity * sizeof(float4)));
-    CHK(hipMalloc((void**)&ctx->ps.g_a, (size_t)capacity * sizeof(float4)));
-    CHK(hipMalloc((void**)&ctx->ps.g_thr, (size_t)capacity * sizeof(float4)));
-    CHK(hipMalloc((void**)&ctx->ps.hit_t, (size_t)capacity * sizeof(float)));
-    CHK(hipMalloc((void**)&ctx->ps.hit_ref, (size_t)capacity * sizeof(int32_t)));
-    CHK(hipMalloc((void**)&ctx->ps.contrib, std::max<size_t>((size_t)capacity * contrib_samples * 3, 1) * sizeof(float)));
-    CHK(hipMalloc((void**)&ctx->ps.sh_o, std::max<size_t>((size_t)capacity * contrib_samples, 1) * sizeof(float4)));
-    CHK(hipMalloc((void**)&ctx->ps.sh_d, std::max<size_t>((size_t)capacity * contrib_samples, 1) * sizeof(float4)));
-    CHK(hipMalloc((void**)&ctx->ps.pid, (size_t)capacity * sizeof(uint32_t)));
-    CHK(hipMalloc((void**)&ctx->ps.o_seed_next, (size_t)capacity * sizeof(float4)));
-    CHK(hipMalloc((void**)&ctx->ps.d_depth_next, (size_t)capacity * sizeof(float4)));
-    CHK(hipMalloc((void**)&ctx->ps.thr_next, (size_t)capacity * sizeof(float4)));
-    CHK(hipMalloc((void**)&ctx->ps.pid_next, (size_t)capacity * sizeof(uint32_t)));
-    CHK(hipMalloc((void**)&ctx->hitq, (size_t)capacity * sizeof(uint32_t)));
-    CHK(hipMalloc((void**)&ctx->gatherq, (size_t)capacity * sizeof(uint32_t)));
-    ctx->ps.capacity = capacity;
+    PathState ps{};
+    uint32_t *hq = nullptr, *gq = nullptr;
+    const size_t bytes = carvePaths(nullptr, capacity, contrib_samples, ps, hq, gq);
+    CHK(hipMalloc(&ctx->path_pool, bytes));  // the only allocation: nothing is left half done when it fails
+    ctx->path_pool_bytes = bytes;
+    carvePaths((char*)ctx->path_pool, capacity, contrib_samples, ctx->ps, ctx->hitq, ctx->gatherq);
     ctx->contrib_samples = contrib_samples;
     return PTC_OK;
 }
@@ -208,6 +250,7 @@ uint32_t samplesPerSegment(const ptc_context* c, uint32_t root) {
 
 hipEvent_t takeEvent(ptc_context* c) {
     if (c->ev_used == c->ev_pool.size()) {
+        if (c->no_alloc) return nullptr;
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) return nullptr;
         c->ev_pool.push_back(e);
@@ -223,8 +266,8 @@ struct Timed {  // brackets a launch with events when profiling is on
     Timed(ptc_context* c_, int kind_, hipStream_t s_ = nullptr) : c(c_), kind(kind_), s(s_ ? s_ : c_->stream) {
         if (c->profile) {
             a = takeEvent(c);
-            b = takeEvent(c);
-            if (a) (void)hipEventRecord(a, s);
+            b = a ? takeEvent(c) : nullptr;
+            if (a && b) (void)hipEventRecord(a, s);
         }
     }
     ~Timed() {
@@ -295,7 +338,9 @@ int makeParams(ptc_context* ctx, int frame_id, uint32_t w, uint32_t h, RenderPar
     rp.max_depth_eff = std::min<uint32_t>(ctx->cfg.maxDepth, ctx->bounce_cap);
     rp.semantics = ctx->semantics;
     rp.seeding = ctx->seeding;
-    rp.cull_zero = ctx->cull_zero;
+    // reference seeding: every segment the reference traces advances the pixel's counter (PinholeCamera.cu:56),
+    // which seeds all later samples of the pixel, so a dead path has to be traced to its end
+    rp.cull_zero = ctx->cull_zero && ctx->seeding == 1;
     rp.brute_force = ctx->brute_force;
     rp.root_light_samples = (uint32_t)(int)sqrtf((float)ctx->light_samples);
     rp.samples_per_path = samplesPerSegment(ctx, rp.root_light_samples);
@@ -310,11 +355,9 @@ int makeParams(ptc_context* ctx, int frame_id, uint32_t w, uint32_t h, RenderPar
 }
 
 int uploadLights(ptc_context* ctx) {
-    if (!ctx->lights_dirty) return PTC_OK;
     CHK(upload(ctx->d_plights, ctx->plights, ctx->stream));
     CHK(upload(ctx->d_dlights, ctx->dlights, ctx->stream));
     CHK(upload(ctx->d_qlights, ctx->qlights, ctx->stream));
-    ctx->lights_dirty = false;
     return PTC_OK;
 }
 
@@ -391,47 +434,10 @@ int runBounces(ptc_context* ctx, const RenderParams& rp, const DevScene& sc, uin
     return PTC_OK;
 }
 
-int renderRange(ptc_context* ctx, int frame_id, uint32_t w, uint32_t h, int32_t j0, int32_t j1, int clear) {
-    RenderParams rp;
-    int rc = makeParams(ctx, frame_id, w, h, rp);
-    if (rc) return rc;
-    if (j0 < 0 || j1 < j0) return fail(ctx, PTC_ERR_INVALID, "bad sample range");
-    if ((uint32_t)j1 > (1u << 20)) return fail(ctx, PTC_ERR_INVALID, "at most 2^20 samples per pixel");
-    rc = ensureTargets(ctx, w, h);
-    if (rc) return rc;
-    rc = uploadLights(ctx);
-    if (rc) return rc;
-    const size_t npix = (size_t)w * h;
-    if (clear) {
-        CHK(hipMemsetAsync(ctx->acc, 0, npix * 3 * sizeof(float), ctx->stream));
-        if (j0 == 0) {
-            CHK(hipMemsetAsync(ctx->segctr, 0, (size_t)ctx->npix_pad * sizeof(uint32_t), ctx->stream));
-            ctx->ref_next_sample = 0;
-        }
-    }
-    if (rp.seeding == 0 && j1 > j0 && j0 != ctx->ref_next_sample)
-        return fail(ctx, PTC_ERR_INVALID, "reference seeding depends on the pixel's earlier samples: ranges must start at 0 (with clear) or continue the previous range");
+// Samples [j0, j1) of every pixel, `per_batch` samples per wavefront batch, into ctx->acc.  The render
+// targets and the path arrays are in place; nothing is allocated here.
+int renderBatches(ptc_context* ctx, RenderParams& rp, int32_t j0, int32_t j1, uint64_t per_batch) {
     const DevScene sc = deviceScene(ctx);
-    const uint32_t S = rp.samples_per_path;
-    // samples of every pixel per batch
-    uint64_t per_batch = rp.seeding == 0 ? 1u : std::max<uint64_t>(1u, ctx->batch_paths / ctx->npix_pad);
-    {
-        // device memory one path of a batch takes: the packed state twice, L, hit, gather record, two
-        // queue entries, and per light sample its term and its shadow-ray record; a batch may take
-        // half of what the device has free (counting what this context already holds for paths)
-        const uint64_t per_path = 2u * (48u + 4u) + 16u + 8u + 32u + 8u + (uint64_t)S * (12u + 32u);
-        size_t free_b = 0, total_b = 0;
-        CHK(hipMemGetInfo(&free_b, &total_b));
-        const uint64_t held = (uint64_t)ctx->ps.capacity * (2u * (48u + 4u) + 16u + 8u + 32u + 8u + (uint64_t)ctx->contrib_samples * (12u + 32u));
-        const uint64_t fit = ((uint64_t)free_b + held) / 2u / per_path;
-        per_batch = std::max<uint64_t>(1u, std::min<uint64_t>(per_batch, fit / ctx->npix_pad));
-        // 32-bit indices into the per-sample arrays
-        if (S) per_batch = std::max<uint64_t>(1u, std::min<uint64_t>(per_batch, 0xFFFFFF00ull / ((uint64_t)ctx->npix_pad * S)));
-    }
-    per_batch = std::min<uint64_t>(per_batch, (uint64_t)std::max(1, j1 - j0));
-    if ((uint64_t)ctx->npix_pad * per_batch > 0xFFFFFFF0ull) return fail(ctx, PTC_ERR_INVALID, "batch too large");
-    rc = ensurePaths(ctx, (uint32_t)(ctx->npix_pad * per_batch), S);
-    if (rc) return rc;
     for (int32_t ja = j0; ja < j1; ja += (int32_t)per_batch) {
         const uint32_t ns = (uint32_t)std::min<int64_t>((int64_t)per_batch, j1 - ja);
         rp.batch_samples = ns;
@@ -447,7 +453,7 @@ int renderRange(ptc_context* ctx, int frame_id, uint32_t w, uint32_t h, int32_t 
         CHK(hipStreamSynchronize(ctx->stream));
         const uint32_t count0 = *ctx->h_count;
         ctx->stats.paths += count0;
-        rc = runBounces(ctx, rp, sc, count0, (uint32_t)ja);
+        const int rc = runBounces(ctx, rp, sc, count0, (uint32_t)ja);
         if (rc) return rc;
         {
             Timed t(ctx, 3);
@@ -458,8 +464,56 @@ int renderRange(ptc_context* ctx, int frame_id, uint32_t w, uint32_t h, int32_t 
             collectSpans(ctx);
         }
     }
-    if (rp.seeding == 0) ctx->ref_next_sample = j1;
     CHK(hipGetLastError());
+    return PTC_OK;
+}
+
+int checkRange(ptc_context* ctx, int32_t j0, int32_t j1) {
+    if (j0 < 0 || j1 < j0) return fail(ctx, PTC_ERR_INVALID, "bad sample range");
+    if ((uint32_t)j1 > (1u << 20)) return fail(ctx, PTC_ERR_INVALID, "at most 2^20 samples per pixel");
+    return PTC_OK;
+}
+
+int renderRange(ptc_context* ctx, int frame_id, uint32_t w, uint32_t h, int32_t j0, int32_t j1, int clear) {
+    RenderParams rp;
+    int rc = makeParams(ctx, frame_id, w, h, rp);
+    if (rc) return rc;
+    rc = checkRange(ctx, j0, j1);
+    if (rc) return rc;
+    rc = ensureTargets(ctx, w, h);
+    if (rc) return rc;
+    const size_t npix = (size_t)w * h;
+    if (clear) {
+        CHK(hipMemsetAsync(ctx->acc, 0, npix * 3 * sizeof(float), ctx->stream));
+        if (j0 == 0) {
+            CHK(hipMemsetAsync(ctx->segctr, 0, (size_t)ctx->npix_pad * sizeof(uint32_t), ctx->stream));
+            ctx->ref_next_sample = 0;
+        }
+    }
+    if (rp.seeding == 0 && j1 > j0 && j0 != ctx->ref_next_sample)
+        return fail(ctx, PTC_ERR_INVALID, "reference seeding depends on the pixel's earlier samples: ranges must start at 0 (with clear) or continue the previous range");
+    const uint32_t S = rp.samples_per_path;
+    // samples of every pixel per batch
+    uint64_t per_batch = rp.seeding == 0 ? 1u : std::max<uint64_t>(1u, ctx->batch_paths / ctx->npix_pad);
+    {
+        // a batch may take half of what the device has free (counting what this context already holds for paths)
+        const uint64_t per_path = bytesPerPath(S);
+        size_t free_b = 0, total_b = 0;
+        CHK(hipMemGetInfo(&free_b, &total_b));
+        const uint64_t fit = ((uint64_t)free_b + ctx->path_pool_bytes) / 2u / per_path;
+        per_batch = std::max<uint64_t>(1u, std::min<uint64_t>(per_batch, fit / ctx->npix_pad));
+        // 32-bit indices into the per-sample arrays
+        if (S) per_batch = std::max<uint64_t>(1u, std::min<uint64_t>(per_batch, 0xFFFFFF00ull / ((uint64_t)ctx->npix_pad * S)));
+    }
+    per_batch = std::min<uint64_t>(per_batch, (uint64_t)std::max(1, j1 - j0));
+    if ((uint64_t)ctx->npix_pad * per_batch > 0xFFFFFFF0ull) return fail(ctx, PTC_ERR_INVALID, "batch too large");
+    rc = ensurePaths(ctx, (uint32_t)(ctx->npix_pad * per_batch), S);
+    if (rc) return rc;
+    ctx->stats.batch_paths = std::max<uint64_t>(ctx->stats.batch_paths, ctx->npix_pad * per_batch);
+    ctx->stats.path_state_bytes = ctx->path_pool_bytes;
+    rc = renderBatches(ctx, rp, j0, j1, per_batch);
+    if (rc) return rc;
+    if (rp.seeding == 0) ctx->ref_next_sample = j1;
     return PTC_OK;
 }
 
@@ -503,7 +557,7 @@ int ptc_create(int device_ordinal, ptc_context** out) {
     ctx->device = device_ordinal;
     auto bail = [&](const char* what, hipError_t err) {
         g_create_error = std::string(what) + ": " + hipGetErrorString(err);
-        delete ctx;
+        (void)ptc_destroy(ctx);  // releases whatever exists so far
         return PTC_ERR_DEVICE;
     };
     if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
@@ -511,6 +565,8 @@ int ptc_create(int device_ordinal, ptc_context** out) {
     if ((e = hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     if ((e = hipEventCreateWithFlags(&ctx->ev_shadow, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&ctx->ev_gather, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreate(&ctx->ev_t0)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreate(&ctx->ev_t1)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipMalloc((void**)&ctx->qcount, N_QCOUNT * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void**)&ctx->counters, N_COUNTERS * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMemset(ctx->counters, 0, N_COUNTERS * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
@@ -536,6 +592,8 @@ int ptc_destroy(ptc_context* ctx) {
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->ev_shadow) (void)hipEventDestroy(ctx->ev_shadow);
     if (ctx->ev_gather) (void)hipEventDestroy(ctx->ev_gather);
+    if (ctx->ev_t0) (void)hipEventDestroy(ctx->ev_t0);
+    if (ctx->ev_t1) (void)hipEventDestroy(ctx->ev_t1);
     delete ctx;
     return PTC_OK;
 }
@@ -599,8 +657,7 @@ int ptc_set_lights(ptc_context* ctx, const PtcPointLight* pl, size_t np, const P
     ctx->plights.assign(pl, pl + np);
     ctx->dlights.assign(dl, dl + nd);
     ctx->qlights.assign(ql, ql + nq);
-    ctx->lights_dirty = true;
-    return PTC_OK;
+    return uploadLights(ctx);  // device copies are made here, so that no render call has to allocate
 }
 
 int ptc_set_background(ptc_context* ctx, float r, float g, float b) {
@@ -614,9 +671,7 @@ int ptc_set_background(ptc_context* ctx, float r, float g, float b) {
 int ptc_build(ptc_context* ctx) {
     ENTER();
     CHK(hipStreamSynchronize(ctx->stream));
-    hipEvent_t e0, e1;
-    CHK(hipEventCreate(&e0));
-    CHK(hipEventCreate(&e1));
+    const hipEvent_t e0 = ctx->ev_t0, e1 = ctx->ev_t1;  // owned by the context: no error path can leak them
     CHK(hipEventRecord(e0, ctx->stream));
     // de-duplicate the per-primitive material copies
     std::map<std::string, uint32_t> ids;
@@ -664,16 +719,12 @@ int ptc_build(ptc_context* ctx) {
     std::string err = bvh_build(ctx->stream, in, ctx->bvh);
     if (!err.empty()) {
         bvh_free(ctx->bvh);
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
         return fail(ctx, PTC_ERR_DEVICE, err);
     }
     CHK(hipEventRecord(e1, ctx->stream));
     CHK(hipEventSynchronize(e1));
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, e0, e1);
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     ctx->stats.build_ms = ms;
     ctx->stats.bvh_nodes = ctx->bvh.n_nodes;
     ctx->stats.bvh_max_depth = ctx->bvh.max_depth;
@@ -819,7 +870,7 @@ int ptc_set_option(ptc_context* ctx, int option, int64_t value) {
 int ptc_collapse_wide(const void* binary_nodes, uint32_t n_nodes, void* wide_nodes_out, uint32_t capacity, uint32_t* n_wide_out, uint32_t* depth_out) {
     if (!binary_nodes || !wide_nodes_out || !n_wide_out || !depth_out || n_nodes == 0) return PTC_ERR_INVALID;
     const int rc = bvh_collapse_wide_host((const BvhNode*)binary_nodes, n_nodes, (WideNode*)wide_nodes_out, capacity, n_wide_out, depth_out);
-    return rc == 0 ? PTC_OK : rc == 1 ? PTC_ERR_UNSUPPORTED : PTC_ERR_INVALID;
+    return rc == 0 ? PTC_OK : rc == 1 ? PTC_ERR_UNSUPPORTED : PTC_ERR_INVALID;  // 2 = capacity, 3 = malformed nodes
 }
 
 int ptc_get_stats(ptc_context* ctx, PtcStats* out) {
@@ -845,7 +896,10 @@ int ptc_reset_stats(ptc_context* ctx) {
     CHK(hipMemset(ctx->counters, 0, N_COUNTERS * sizeof(unsigned long long)));
     const double build_ms = ctx->stats.build_ms;
     const uint32_t nodes = ctx->stats.bvh_nodes, depth = ctx->stats.bvh_max_depth;
+    const uint64_t pool = ctx->stats.path_state_bytes, bpaths = ctx->stats.batch_paths;
     ctx->stats = PtcStats{};
+    ctx->stats.path_state_bytes = pool;
+    ctx->stats.batch_paths = bpaths;
     ctx->stats.build_ms = build_ms;
     ctx->stats.bvh_nodes = nodes;
     ctx->stats.bvh_max_depth = depth;

@@ -65,5 +65,6 @@ struct BvhBuildOutput {  // device allocations owned by the caller afterwards
 std::string bvh_build(hipStream_t s, const BvhBuildInput& in, BvhBuildOutput& out);
 void bvh_free(BvhBuildOutput& out);
 // Host part of the build on its own: binary nodes -> four-wide nodes.  0 = done, 1 = not representable
-// (non-finite box, too deep), 2 = `capacity` too small.
+// (non-finite box, too deep), 2 = `capacity` too small, 3 = malformed input (a child index outside the
+// array, or a node reached twice).
 int bvh_collapse_wide_host(const BvhNode* bin, uint32_t n_nodes, WideNode* out, uint32_t capacity, uint32_t* n_wide, uint32_t* depth);

@@ -1599,6 +1599,7 @@ void wf_shadow(hipStream_t s, const RenderParams& rp, const DevScene& sc, const 
 
 // Waves of the traversal kernels that the device keeps resident at once.
 uint32_t wf_resident_waves(int device) {
+    (void)deferred_resident_waves();  // fill its per-device cache now (context creation), not inside a render call
     int per_cu = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_extend<false>, BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 4;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;

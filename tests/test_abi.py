@@ -33,7 +33,7 @@ def test_pod_sizes_match_the_header():
     assert C.sizeof(_ffi.QuadLight) == 284 and _ffi.QuadLight.color.offset == 272
     assert C.sizeof(_ffi.Config) == 88 and _ffi.Config.hSize.offset == 48 and _ffi.Config.russian_roul.offset == 80
     assert C.sizeof(_ffi.PointLight) == 36 and C.sizeof(_ffi.DirectionalLight) == 24
-    assert C.sizeof(_ffi.Stats) == 8 * 6 + 8 * 4 + 8 * 4 + 4 * 2 + 8
+    assert C.sizeof(_ffi.Stats) == 8 * 6 + 8 * 4 + 8 * 4 + 4 * 2 + 8 + 8 * 2
 
 
 def test_no_gpu_means_a_loud_error():
@@ -64,3 +64,30 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert not re.search(r"import\s+oracle|from\s+oracle|oracle_py|liboracle|oracle\.h|oracle/|orc_[a-z]+\(", text), os.path.join(dirpath, f)
+
+
+def test_collapse_wide_rejects_malformed_nodes():
+    """Caller-supplied two-child nodes: a child index outside the array, or a node that is reached
+    twice (a cycle included), is PTC_ERR_INVALID, not an out-of-bounds read or an endless loop."""
+    lib = _ffi.core_lib()
+    lib.ptc_collapse_wide.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    node = np.dtype([("box", "<f4", 12), ("child", "<u4", 2), ("pad", "<u4", 2)])
+    assert node.itemsize == 64
+    LEAF = (1 << 30) | 0  # one triangle, slot 0
+
+    def run(children):
+        n = np.zeros(len(children), dtype=node)
+        n["box"][:, 0:3] = 0.0
+        n["box"][:, 3:6] = 1.0
+        n["box"][:, 6:9] = 0.0
+        n["box"][:, 9:12] = 1.0
+        for i, ch in enumerate(children):
+            n["child"][i] = ch
+        out = np.zeros(len(children) * 64 + 64, dtype=np.uint8)
+        nw, depth = C.c_uint32(), C.c_uint32()
+        return lib.ptc_collapse_wide(n.ctypes.data, len(n), out.ctypes.data, len(children) + 1, C.byref(nw), C.byref(depth))
+
+    assert run([(1, LEAF), (LEAF, LEAF)]) == 0
+    assert run([(5, LEAF), (LEAF, LEAF)]) == _ffi.ERR_INVALID            # child outside the array
+    assert run([(1, LEAF), (0, LEAF)]) == _ffi.ERR_INVALID               # cycle back to the root
+    assert run([(1, 1), (LEAF, LEAF)]) == _ffi.ERR_INVALID               # the same node twice

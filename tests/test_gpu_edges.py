@@ -272,3 +272,36 @@ def test_extreme_coordinates_against_brute_force(far):
         for f in ("prim", "t", "u", "v"):
             assert np.array_equal(hits[f].view(np.uint32), want_hits[f].view(np.uint32)), (hex(tune), f)
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), hex(tune)
+
+
+def test_undersized_sum_buffer_bound_before_the_first_render_is_rejected():
+    """ptc_bind_sum_buffer before any image size is known cannot check the size; the first render
+    must (instead of writing past the end of the caller's buffer)."""
+    import torch
+    scene = SceneLoader().loadText(override_scene_text(scene_text("scene3/cornellRR.test"), size="64 64", spp="1"))
+    r = Renderer(scene, options={_ffi.OPT_SEEDING: 1})
+    small = torch.zeros(64 * 64 * 3 - 1, dtype=torch.float32, device="cuda")
+    r.bind_sum_buffer(small.data_ptr(), small.numel() * 4)
+    with pytest.raises(RuntimeError, match="too small"):
+        r.render_range(0, 1)
+    big = torch.zeros(64 * 64 * 3, dtype=torch.float32, device="cuda")
+    r.bind_sum_buffer(big.data_ptr(), big.numel() * 4)
+    r.render_range(0, 1)
+    r.synchronize()
+    assert float(big.abs().sum()) > 0
+    # after a size change the check still holds
+    r.width, r.height = 96, 64
+    with pytest.raises(RuntimeError, match="too small"):
+        r.render_range(0, 1)
+    r.close()
+
+
+def test_stats_report_the_batch_footprint():
+    scene = SceneLoader().loadText(override_scene_text(scene_text("scene3/cornellRR.test"), size="64 64", spp="4"))
+    r = Renderer(scene, options={_ffi.OPT_SEEDING: 1})
+    r.run()
+    st = r.stats()
+    r.close()
+    assert st.batch_paths == 64 * 64 * 4
+    # one quad light -> one light sample per segment: 220 B per path plus alignment slack
+    assert 220 * st.batch_paths <= st.path_state_bytes <= 220 * st.batch_paths + 18 * 256

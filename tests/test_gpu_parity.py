@@ -254,7 +254,7 @@ def test_sphere_png_from_the_gpu():
     assert (d <= 1).mean() > 0.9999
 
 
-@pytest.mark.parametrize("name,rel,tol", [("cornellRR", "scene3/cornellRR.test", 0.035), ("ggx", "scene4/ggx.test", 0.02)])
+@pytest.mark.parametrize("name,rel,tol", [("cornellRR", "scene3/cornellRR.test", 0.04), ("ggx", "scene4/ggx.test", 0.02)])
 def test_converged_images_match_the_reference(name, rel, tol):
     """Full-size renders at the scene's own settings (`intended` semantics, reference
     seeding) against the reference's images: relative RMSE of 16x16-pixel block means

@@ -78,7 +78,7 @@ def _strided_blocks(img, stride, block):
     return block_mean(img[::stride, ::stride].astype(np.float64), block)
 
 
-@pytest.mark.parametrize("name,rel,tol", [("cornellRR", "scene3/cornellRR.test", 0.035), ("ggx", "scene4/ggx.test", 0.02)])
+@pytest.mark.parametrize("name,rel,tol", [("cornellRR", "scene3/cornellRR.test", 0.04), ("ggx", "scene4/ggx.test", 0.02)])
 def test_intended_semantics_match_reference_images(name, rel, tol):
     """Every other pixel in x and y at the scene's own 64 spp; 8x8 blocks of those
     (16x16 pixel areas) must agree with the reference image within `tol` relative
@@ -137,6 +137,21 @@ def test_cull_of_zero_throughput_paths_preserves_the_image():
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
         assert sa.extension_rays <= sb.extension_rays
     assert sa.extension_rays < sb.extension_rays  # intended semantics: roulette does kill paths
+
+
+def test_reference_seeding_traces_dead_paths_to_their_end():
+    """Reference seeding: the per-pixel segment counter `i` (PinholeCamera.cu:34,56) advances for every
+    segment the reference traces, dead paths (throughput 0 after Russian roulette, RayTracer.cu:926-928)
+    included, and seeds every later sample of the pixel -- so the zero-throughput cull must not take
+    effect there: cull on/off give the same image AND the same ray counts, and more rays are traced than
+    with counter seeding, where the cull is free to end dead paths."""
+    scene = SceneLoader().loadText(override_scene_text(scene_text("scene3/cornellRR.test"), size="48 48", spp="6"))
+    a, _, sa = orc.render(scene, semantics=1, seeding=0, cull_zero=1, bounce_cap=24)
+    b, _, sb = orc.render(scene, semantics=1, seeding=0, cull_zero=0, bounce_cap=24)
+    c, _, sc = orc.render(scene, semantics=1, seeding=1, cull_zero=1, bounce_cap=24)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert sa.extension_rays == sb.extension_rays and sa.shadow_rays == sb.shadow_rays
+    assert sc.extension_rays < sa.extension_rays
 
 
 def test_counter_seeding_equals_reference_seeding_for_one_sample():
