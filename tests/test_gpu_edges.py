@@ -288,7 +288,7 @@ def test_undersized_sum_buffer_bound_before_the_first_render_is_rejected():
     r.bind_sum_buffer(big.data_ptr(), big.numel() * 4)
     r.render_range(0, 1)
     r.synchronize()
-    assert float(big.abs().sum()) > 0
+    assert int((big != 0).sum()) > 0
     # after a size change the check still holds
     r.width, r.height = 96, 64
     with pytest.raises(RuntimeError, match="too small"):
@@ -303,5 +303,5 @@ def test_stats_report_the_batch_footprint():
     st = r.stats()
     r.close()
     assert st.batch_paths == 64 * 64 * 4
-    # one quad light -> one light sample per segment: 220 B per path plus alignment slack
-    assert 220 * st.batch_paths <= st.path_state_bytes <= 220 * st.batch_paths + 18 * 256
+    # one quad light -> one light sample per segment: 212 B per path plus alignment slack
+    assert 212 * st.batch_paths <= st.path_state_bytes <= 212 * st.batch_paths + 18 * 256
