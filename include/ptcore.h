@@ -230,6 +230,23 @@ int  ptc_render(ptc_context* ctx, int frame_id, uint32_t width, uint32_t height)
  * ptc_synchronize (or any later operation on the same stream). */
 int  ptc_render_range(ptc_context* ctx, int frame_id, uint32_t width, uint32_t height,
                       int32_t spp_begin, int32_t spp_end, int clear);
+/* No counterpart in the reference.  For callers that cannot allocate device memory (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc): ptc_render_range with every
+ * per-path and per-pixel work array taken from a fixed array in device memory that the library holds on
+ * each GPU it runs on (PTC_STATIC_SCRATCH_MIB MiB, until the process ends) instead of from allocations.
+ * The call allocates and frees nothing.  Samples [spp_begin, spp_end) of every pixel are added to the
+ * caller's `sums_device` (device memory, width*height*3 floats, same indexing as ptc_read_sum; cleared
+ * first when clear != 0); the context's own sum buffer and result are not touched.  The stream is
+ * synchronised before the call returns.  One sample of every pixel of the image, padded to whole 64x64
+ * pixel blocks, must fit: (256 + 44 x light samples per segment) bytes per padded pixel, i.e. up to
+ * about 400x400 pixels with two quad lights; larger images -> PTC_ERR_INVALID with a message that
+ * says so.  Scene, lights and options must be set up (ptc_set_*, ptc_build) before, with the ordinary
+ * calls.  With reference seeding the range must start at 0 with clear (no per-pixel history is kept
+ * between calls).  All contexts of a process on one GPU share that GPU's array: calls that overlap in
+ * time on one GPU race and must be serialised by the caller. */
+#define PTC_STATIC_SCRATCH_MIB 48
+int  ptc_render_range_static(ptc_context* ctx, int frame_id, uint32_t width, uint32_t height,
+                             int32_t spp_begin, int32_t spp_end, int clear, void* sums_device, size_t sums_bytes);
 /* Build-only: result = pow(sum / total_spp, 1/gamma) (frame 1) or the frame
  * lerp of PinholeCamera.cu:75-80. */
 int  ptc_resolve(ptc_context* ctx, int frame_id, int32_t total_spp);

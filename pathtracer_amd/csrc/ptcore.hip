@@ -13,14 +13,25 @@
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "ptcore.h"
 #include "wavefront.h"
 
+// Device memory of ptc_render_range_static: the per-path arrays of a batch and the two per-pixel seed
+// arrays live here instead of in allocations.  Every GPU the library runs on holds its own copy of the
+// array at its own address; host code only ever uses the address hipGetSymbolAddress returned for the
+// device at hand (g_scratch_ptr), never the array's name.
+#define PTC_STATIC_SCRATCH_BYTES ((size_t)PTC_STATIC_SCRATCH_MIB << 20)
+static __device__ __align__(256) unsigned char g_static_scratch[PTC_STATIC_SCRATCH_BYTES];
+
 namespace {
 std::string g_create_error;
+constexpr int kMaxDevices = 64;
+unsigned char* g_scratch_ptr[kMaxDevices] = {nullptr};  // per device: address of g_static_scratch there
+std::mutex g_scratch_mutex;
 const char* kIntegrators[] = {"raytracer", "analyticdirect", "direct", "pathtracer", "pathtracer2"};
 }  // namespace
 
@@ -572,6 +583,14 @@ int ptc_create(int device_ordinal, ptc_context** out) {
     if ((e = hipMemset(ctx->counters, 0, N_COUNTERS * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
     if ((e = hipHostMalloc((void**)&ctx->h_count, sizeof(uint32_t))) != hipSuccess) return bail("hipHostMalloc", e);
     ctx->resident_waves = wf_resident_waves(device_ordinal);
+    if (device_ordinal < kMaxDevices) {  // once per device, with that device current
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (!g_scratch_ptr[device_ordinal]) {
+            void* p = nullptr;
+            if ((e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_static_scratch))) != hipSuccess) return bail("hipGetSymbolAddress", e);
+            g_scratch_ptr[device_ordinal] = (unsigned char*)p;
+        }
+    }
     *out = ctx;
     return PTC_OK;
 }
@@ -735,6 +754,73 @@ int ptc_build(ptc_context* ctx) {
 int ptc_render_range(ptc_context* ctx, int frame_id, uint32_t width, uint32_t height, int32_t spp_begin, int32_t spp_end, int clear) {
     ENTER();
     return renderRange(ctx, frame_id, width, height, spp_begin, spp_end, clear);
+}
+
+int ptc_render_range_static(ptc_context* ctx, int frame_id, uint32_t width, uint32_t height, int32_t spp_begin, int32_t spp_end, int clear,
+                            void* sums_device, size_t sums_bytes) {
+    ENTER();
+    RenderParams rp;
+    int rc = makeParams(ctx, frame_id, width, height, rp);
+    if (rc) return rc;
+    rc = checkRange(ctx, spp_begin, spp_end);
+    if (rc) return rc;
+    if (width == 0 || height == 0) return fail(ctx, PTC_ERR_INVALID, "image size must be non-zero");
+    const size_t npix = (size_t)width * height;
+    if (!sums_device || sums_bytes < npix * 3 * sizeof(float)) return fail(ctx, PTC_ERR_INVALID, "sum buffer missing or too small for this image size");
+    unsigned char* const scratch = ctx->device < kMaxDevices ? g_scratch_ptr[ctx->device] : nullptr;
+    if (!scratch) return fail(ctx, PTC_ERR_UNSUPPORTED, "no static scratch on this device");
+    if (rp.seeding == 0 && spp_end > spp_begin && !(spp_begin == 0 && clear))
+        return fail(ctx, PTC_ERR_INVALID, "reference seeding: the static scratch keeps no history between calls, ranges must start at 0 with clear");
+    // layout of the scratch array: per-pixel segment counters, per-pixel jitter seeds, per-path arrays
+    const uint64_t npix_pad = paddedPixels(width, height);
+    const uint32_t S = rp.samples_per_path;
+    const size_t head = 2 * (((size_t)npix_pad * sizeof(uint32_t) + 255u) & ~(size_t)255u);
+    PathState ps{};
+    uint32_t *hq = nullptr, *gq = nullptr;
+    uint64_t per_batch = rp.seeding == 0 ? 1u : std::max<uint64_t>(1u, std::min<uint64_t>(ctx->batch_paths / npix_pad, (uint64_t)std::max(1, spp_end - spp_begin)));
+    const uint64_t room = PTC_STATIC_SCRATCH_BYTES > head ? (PTC_STATIC_SCRATCH_BYTES - head) / (bytesPerPath(S) + 1u) : 0u;  // paths, roughly
+    per_batch = std::min<uint64_t>(per_batch, std::max<uint64_t>(1u, room / npix_pad));
+    while (per_batch > 1u && (npix_pad * per_batch > 0xFFFFFFF0ull || head + carvePaths(nullptr, (uint32_t)(npix_pad * per_batch), S, ps, hq, gq) > PTC_STATIC_SCRATCH_BYTES)) --per_batch;
+    if (npix_pad > 0xFFFFF000ull || (S && npix_pad * S > 0xFFFFFF00ull) ||
+        head + carvePaths(nullptr, (uint32_t)npix_pad, S, ps, hq, gq) > PTC_STATIC_SCRATCH_BYTES)
+        return fail(ctx, PTC_ERR_INVALID, "image too large for the static scratch (" + std::to_string(PTC_STATIC_SCRATCH_MIB) + " MiB): one sample of every pixel of the image, padded to 64x64 blocks, needs " +
+                                              std::to_string(bytesPerPath(S) + 8u) + " bytes per pixel with " + std::to_string(S) + " light samples per segment");
+    // the context's own arrays step aside for the duration of the call
+    struct Saved {
+        PathState ps;
+        uint32_t *hitq, *gatherq, *segctr, *pixseed, contrib_samples, width, height, npix_pad;
+        float* acc;
+        bool no_alloc;
+    } const saved = {ctx->ps, ctx->hitq, ctx->gatherq, ctx->segctr, ctx->pixseed, ctx->contrib_samples, ctx->width, ctx->height, ctx->npix_pad, ctx->acc, ctx->no_alloc};
+    ctx->segctr = (uint32_t*)scratch;
+    ctx->pixseed = (uint32_t*)(scratch + head / 2);
+    carvePaths((char*)scratch + head, (uint32_t)(npix_pad * per_batch), S, ctx->ps, ctx->hitq, ctx->gatherq);
+    ctx->contrib_samples = S;
+    ctx->npix_pad = (uint32_t)npix_pad;
+    ctx->acc = (float*)sums_device;
+    ctx->no_alloc = true;
+    auto run = [&]() -> int {
+        // the array keeps the last call's contents: what must start at zero is cleared here
+        if (rp.seeding == 0) CHK(hipMemsetAsync(ctx->segctr, 0, (size_t)npix_pad * sizeof(uint32_t), ctx->stream));
+        if (clear) CHK(hipMemsetAsync(ctx->acc, 0, npix * 3 * sizeof(float), ctx->stream));
+        const int r = renderBatches(ctx, rp, spp_begin, spp_end, per_batch);
+        if (r) return r;
+        CHK(hipStreamSynchronize(ctx->stream));  // the scratch is free for the next call when this one returns
+        return PTC_OK;
+    };
+    rc = run();
+    ctx->ps = saved.ps;
+    ctx->hitq = saved.hitq;
+    ctx->gatherq = saved.gatherq;
+    ctx->segctr = saved.segctr;
+    ctx->pixseed = saved.pixseed;
+    ctx->contrib_samples = saved.contrib_samples;
+    ctx->width = saved.width;
+    ctx->height = saved.height;
+    ctx->npix_pad = saved.npix_pad;
+    ctx->acc = saved.acc;
+    ctx->no_alloc = saved.no_alloc;
+    return rc;
 }
 
 int ptc_resolve(ptc_context* ctx, int frame_id, int32_t total_spp) {

@@ -98,6 +98,12 @@ class Renderer:
     def render_range(self, spp_begin, spp_end, clear=True, frame_id=1):
         self._check(self._lib.ptc_render_range(self._ctx, frame_id, self.width, self.height, spp_begin, spp_end, int(clear)))
 
+    def render_range_static(self, spp_begin, spp_end, sums_device_ptr, sums_bytes, clear=True, frame_id=1):
+        """ptc_render_range_static: the same samples added to the caller's device buffer, with all
+        work arrays in the library's fixed scratch array (no allocation during the call)."""
+        self._check(self._lib.ptc_render_range_static(self._ctx, frame_id, self.width, self.height, spp_begin, spp_end, int(clear),
+                                                      C.c_void_p(sums_device_ptr), sums_bytes))
+
     def resolve(self, total_spp, frame_id=1):
         self._check(self._lib.ptc_resolve(self._ctx, frame_id, total_spp))
 
