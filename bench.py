@@ -1,22 +1,29 @@
 #!/usr/bin/env python3
 """Benchmark of the path-tracing hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload dragon|cornell|cornell_ggx]
+    python bench.py --gpus N --steps K --warmup W [--workload dragon|dragon_4k|cornell|cornell_ggx|sphere]
+                    [--strong] [--semantics 0|1] [--ordered-reduce]
 
-A step = one full render of the workload (every pixel x every sample) through the
-C ABI: generate -> (extend -> surface -> shadow -> gather)* -> accumulate, plus, for N > 1, one
-RCCL reduce of the pre-gamma radiance sums to rank 0 and the resolve there.  Inputs
-(scene, BVH) are resident in HBM before the timed region.  With N > 1 every rank
-renders its own `spp` samples of every pixel (global sample indices
-[rank*spp, (rank+1)*spp), counter-based seeds), i.e. weak scaling.
+A step = one full render of the workload (every pixel x every sample of this rank's share) through
+the C ABI: generate -> (extend -> surface -> shadow -> gather)* -> accumulate, plus, for N > 1, one
+RCCL reduce of the pre-gamma radiance sums to rank 0 and the resolve there.  Inputs (scene, BVH) are
+resident in HBM before the timed region.
 
-Prints ONE JSON line: Mrays/s (extension segments = paths x bounces, whole job), the
-roofline object of the dominant kernel class (extension-ray traversal) and the
-CPU-oracle baseline.
+N > 1: one process per GPU.  Started by a launcher (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+environment) this file is one rank; started plainly with --gpus N it starts N fresh ranks of itself
+before anything here touches a GPU, relays rank 0's line and fails if any rank fails.  Weak scaling
+(default): every rank renders the workload's own samples per pixel, global sample indices
+[rank*spp, (rank+1)*spp), counter-based seeds.  --strong: the workload's samples are divided among the
+ranks.
+
+Prints ONE JSON line: Mrays/s (extension segments = paths x bounces, whole job), the roofline object
+of the dominant kernel class (extension-ray traversal) and the CPU-oracle baseline.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,6 +38,10 @@ WORKLOADS = {
     # BASELINE.json configs[3]: Stanford dragon GGX, 1080p, 256 spp (BVH-traversal bound)
     "dragon": dict(scene="scene4/dragon.test", over=dict(size="1920 1080", spp="256"),
                    name="Stanford dragon (100006 tris, 2 quad lights) GGX BRDF sampling + NEE + RR, maxdepth 5, 1920x1080, 256 spp"),
+    # BASELINE.json configs[4]: the same scene at 3840x2160, 4096 spp over 8 GPUs = 512 spp per GPU (weak
+    # scaling reaches the configuration at N = 8; --strong --spp 4096 divides it at any N)
+    "dragon_4k": dict(scene="scene4/dragon.test", over=dict(size="3840 2160", spp="512"),
+                      name="Stanford dragon (100006 tris, 2 quad lights) GGX BRDF sampling + NEE + RR, maxdepth 5, 3840x2160, 512 spp per GPU (4096 spp on 8 GPUs)"),
     # configs[1]: Cornell box Phong, NEE + Russian roulette, 512x512, 1024 spp
     "cornell": dict(scene="scene3/cornellRR.test", over=dict(size="512 512", spp="1024"),
                     name="Cornell box Phong, NEE + Russian roulette, maxdepth -1, 512x512, 1024 spp"),
@@ -39,11 +50,13 @@ WORKLOADS = {
                         name="Cornell box, GGX sphere (roughness 0.25), BRDF importance sampling + NEE + RR, 512x512, 4096 spp"),
 }
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak
+CUS, SIMDS_PER_CU = 256, 4
+VALU_CYCLES_PER_WAVE_INST = 2.0   # a wave64 VALU instruction occupies a 32-lane SIMD for 2 cycles
 
 
-def build_scene(workload, spp_override=None, size_override=None):
-    from pathtracer_amd import SceneLoader, override_scene_text
+def scene_text_for(workload, spp_override=None, size_override=None):
+    from pathtracer_amd import override_scene_text
     w = WORKLOADS[workload]
     text = open(os.path.join(ROOT, "scenes", w["scene"])).read()
     over = dict(w["over"])
@@ -54,10 +67,15 @@ def build_scene(workload, spp_override=None, size_override=None):
     text = override_scene_text(text, **over)
     if w.get("ggx_sphere"):
         text = text.replace("#sphere\n", "#sphere\nbrdf ggx\nroughness 0.25\n", 1)
-    return SceneLoader().loadText(text)
+    return text
 
 
-def main():
+def build_scene(workload, spp_override=None, size_override=None):
+    from pathtracer_amd import SceneLoader
+    return SceneLoader().loadText(scene_text_for(workload, spp_override, size_override))
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -66,13 +84,79 @@ def main():
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (invalidates the headline config)")
     ap.add_argument("--size", default="", help='override "W H" (invalidates the headline config)')
     ap.add_argument("--semantics", type=int, default=1, help="1 = intended (by-reference helpers), 0 = literal")
+    ap.add_argument("--strong", action="store_true", help="divide the workload's samples among the ranks (default: every rank renders all of them)")
+    ap.add_argument("--ordered-reduce", action="store_true", help="gather the ranks' sums and add them in rank order on rank 0 (deterministic) instead of one sum-reduce")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--batch", type=int, default=None, help="PTC_OPT_BATCH_PATHS")
-    ap.add_argument("--builder", type=int, default=None, help="PTC_OPT_BVH_BUILDER: 0 LBVH, 1 PLOC")
+    ap.add_argument("--builder", type=int, default=None, help="PTC_OPT_BVH_BUILDER")
     ap.add_argument("--tune", type=lambda v: int(v, 0), default=None, help="PTC_OPT_TUNE_TRAVERSAL value (experiments)")
-    args = ap.parse_args()
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="ranks only join a gloo group on the CPU and count themselves (tests the launcher without GPUs)")
+    return ap.parse_args(argv)
 
+
+# ------------------------------------------------------------------------------ launcher --
+def launch_ranks(n, argv):
+    """Start n fresh ranks of this file (one per GPU), relay rank 0's stdout, fail if any rank fails.
+    Nothing in this process touches a GPU (torch is not even imported)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].stdout.read().decode()
+    rcs = []
+    deadline = time.time() + 1800
+    for p in procs:
+        try:
+            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rcs.append(-9)
+    if any(rcs):
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        sys.stderr.write(f"bench.py: ranks exited with {rcs}\n")
+        return 1
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return 0
+
+
+def launcher_selftest(rank, world):
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    joined = torch.ones(1, dtype=torch.int64)
+    dist.all_reduce(joined)
+    if rank == 0:
+        print(json.dumps({"launcher_selftest": True, "ranks_joined": int(joined[0]), "backend": "gloo", "n_gpus": 0}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
+
+
+# -------------------------------------------------------------------------------- one rank --
+def quoted_counters(workload, semantics, overridden):
+    """Per-launch hardware-counter figures of the traversal kernels for this workload, as committed by
+    tools/pmc_summary.py from rocprofv3 --pmc passes of this same command (they cannot be collected
+    inside a normal run)."""
+    path = os.path.join(ROOT, "pmc_counters.json")
+    if overridden or not os.path.exists(path):
+        return None
+    try:
+        data = json.load(open(path))
+    except ValueError:
+        return None
+    return data.get(f"{workload}/semantics{semantics}")
+
+
+def run_rank(args):
     import torch
     import torch.distributed as dist
     from pathtracer_amd import Renderer, _ffi
@@ -81,17 +165,33 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.launcher_selftest:
+        return launcher_selftest(rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank} wants GPU {local_rank} but only {torch.cuda.device_count()} are visible")
     torch.cuda.set_device(local_rank)
+    joined = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        j = torch.ones(1, dtype=torch.int64, device="cuda")
+        dist.all_reduce(j)  # the ranks that really joined the RCCL group
+        joined = int(j[0])
+        if joined != world:
+            raise SystemExit(f"{joined} of {world} ranks joined")
 
     scene = build_scene(args.workload, args.spp or None, args.size or None)
-    spp = scene.samples_per_pixel
+    spp_job = scene.samples_per_pixel
+    if args.strong:
+        if spp_job % world:
+            raise SystemExit(f"--strong: {spp_job} samples do not divide among {world} ranks")
+        spp = spp_job // world
+    else:
+        spp = spp_job
     W, H = scene.width, scene.height
 
     opts = {_ffi.OPT_SEMANTICS: args.semantics, _ffi.OPT_SEEDING: 1}
@@ -108,7 +208,7 @@ def main():
 
     def step():
         # this rank's share of the global sample index space, then one RCCL reduce
-        split_render_step(r, sums, rank, world, spp, dist)
+        split_render_step(r, sums, rank, world, spp, dist, ordered=args.ordered_reduce)
 
     def sync():
         torch.cuda.synchronize()
@@ -151,46 +251,67 @@ def main():
     ext_rays, shadow_rays, paths = (float(x) for x in counts)
 
     if rank == 0:
-        # Extension-ray traversal (k_trace_deferred<false>; k_extend_static for tiny hierarchies)
-        # is the kernel class the roofline is quoted on.  Algorithmic bytes per extension ray: the
-        # queue entry (4 B) and the ray (2 x float4 = 32 B) read, the hit (t + ref = 8 B)
-        # written, 64 B per BVH node visited and 48 B per triangle tested.  The shadow-ray
-        # kernel is reported the same way (32 B ray record read, 12 B written when occluded).
+        overridden = bool(args.spp or args.size)
+        # Extension-ray traversal (k_trace_deferred<false>; k_extend_static for tiny hierarchies) is the
+        # kernel class the roofline is quoted on (rank 0's launches).  Times: HIP events on the launch
+        # stream, live.  Instruction and byte counts per ray: hardware counters of the same command,
+        # committed in pmc_counters.json (they need rocprofv3 --pmc passes of their own).
+        launches = max(int(st.extend_launches), 1)
+        extend_s = st.extend_ms * 1e-3
+        rays_per_launch = st.extension_rays / launches
+        avg_launch_s = extend_s / launches if extend_s > 0 else 0.0
+        # algorithmic bytes per extension ray: the ray (2 x float4 = 32 B) read, the hit (t + ref = 8 B) written,
+        # 4 B for the queue slot, 64 B per BVH node visited and 48 B per triangle tested -- served mostly by L1/L2
         b_ext = 44.0 + 64.0 * nodes_per_ray + 48.0 * prims_per_ray
         b_sh = 44.0 + 64.0 * snodes_per_ray + 48.0 * sprims_per_ray
-        extend_s = st.extend_ms * 1e-3
-        achieved = (b_ext * st.extension_rays / extend_s / 1e9) if extend_s > 0 else 0.0
-        launches = max(int(st.extend_launches), 1)
-        traffic = None
-        tpath = os.path.join(ROOT, "pmc_traffic.json")
-        if os.path.exists(tpath) and not (args.spp or args.size):
-            t = json.load(open(tpath))
-            if t.get("workload") == args.workload and "extend" in t:
-                traffic = round(t["extend"]["fetch_bytes_per_launch"] + t["extend"]["write_bytes_per_launch"], 1)
+        on_chip_gbs = (b_ext * st.extension_rays / extend_s / 1e9) if extend_s > 0 else 0.0
+        q = quoted_counters(args.workload, args.semantics, overridden)
         roofline = {
-            "bound": "hbm", "kernel": "extension-ray traversal (k_trace_deferred<false> over four-wide nodes; k_extend_static for hierarchies of at most 64 nodes)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "algorithmic_bytes_per_launch": round(b_ext * st.extension_rays / launches, 1),
-            "bytes_per_ray": round(b_ext, 1), "nodes_per_ray": round(nodes_per_ray, 2), "prims_per_ray": round(prims_per_ray, 2),
-            "avg_launch_ms": round(st.extend_ms / launches, 4), "launches": int(st.extend_launches),
-            "rays_per_launch": round(st.extension_rays / launches, 1),
+            "kernel": "extension-ray traversal (k_trace_deferred<false> over four-wide nodes; k_extend_static for hierarchies of at most 64 nodes)",
+            "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": int(st.extend_launches), "rays_per_launch": round(rays_per_launch, 1),
+            "nodes_per_ray": round(nodes_per_ray, 2), "prims_per_ray": round(prims_per_ray, 2),
+            "algorithmic_bytes_per_ray": round(b_ext, 1), "algorithmic_bytes_per_launch": round(b_ext * rays_per_launch, 1),
+            "on_chip_GBs": round(on_chip_gbs, 1),
+            "on_chip_note": "algorithmic bytes / kernel time; node and triangle records are served by L1/L2, so this is NOT a fraction of the HBM peak",
             "kernel_ms": {"extend": round(st.extend_ms, 2), "shadow": round(st.connect_ms, 2), "surface+gather": round(st.shade_ms, 2), "other": round(st.other_ms, 2)},
-            "shadow": {"bytes_per_ray": round(b_sh, 1), "nodes_per_ray": round(snodes_per_ray, 2), "prims_per_ray": round(sprims_per_ray, 2),
+            "shadow": {"algorithmic_bytes_per_ray": round(b_sh, 1), "nodes_per_ray": round(snodes_per_ray, 2), "prims_per_ray": round(sprims_per_ray, 2),
                        "rays": int(st.shadow_rays)},
         }
+        if q and avg_launch_s > 0:
+            e = q["extend"]
+            clock_ghz = e["clock_ghz"]
+            valu_rate = e["valu_insts_per_ray"] * rays_per_launch / avg_launch_s          # wave instructions per second
+            valu_peak = CUS * SIMDS_PER_CU * clock_ghz * 1e9 / VALU_CYCLES_PER_WAVE_INST
+            hbm_bytes = e["hbm_bytes_per_ray"] * rays_per_launch
+            roofline.update({
+                "bound": "valu", "achieved": round(valu_rate / 1e9, 1), "peak": round(valu_peak / 1e9, 1), "unit": "G wave-instructions/s",
+                "frac": round(valu_rate / valu_peak, 4),
+                "peak_note": f"{CUS} CUs x {SIMDS_PER_CU} SIMDs x {clock_ghz:.3f} GHz (GRBM_GUI_ACTIVE / 8 / kernel time in the counter pass) / {VALU_CYCLES_PER_WAVE_INST:.0f} cycles per wave64 instruction",
+                "valu_insts_per_ray": round(e["valu_insts_per_ray"], 1), "active_lane_frac": round(e["active_lane_frac"], 3),
+                "salu_per_valu": round(e["salu_per_valu"], 3),
+                "traffic": round(hbm_bytes, 1),
+                "traffic_note": "HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) per ray from the committed counter passes x this run's rays per launch; quoted, not measured in this run",
+                "hbm_GBs": round(hbm_bytes / avg_launch_s / 1e9, 1), "hbm_peak_GBs": HBM_PEAK_GBS, "hbm_frac": round(hbm_bytes / avg_launch_s / 1e9 / HBM_PEAK_GBS, 4),
+                "counters_from": q.get("source", "pmc_counters.json"),
+            })
+        else:
+            roofline.update({"bound": "valu", "achieved": None, "peak": None, "unit": "G wave-instructions/s", "frac": None, "traffic": None,
+                             "note": "no committed counter passes for this workload / override: only event-timed figures"})
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(args, scene)
         out = {
             "metric": "Mrays/s (paths x bounces)", "value": round(ext_rays / dt / 1e6, 2), "unit": "Mrays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": WORKLOADS[args.workload]["name"] + (" [overridden]" if (args.spp or args.size) else ""),
-                       "width": W, "height": H, "spp_per_gpu": spp, "semantics": "intended" if args.semantics else "literal",
-                       "seeding": "counter", "parallelism": f"spp-split x{world}"},
+            "n_gpus": joined, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "the reference's own scene file (scenes/" + WORKLOADS[args.workload]["scene"] + ") at the config's size and sample count; nothing synthetic, no weights",
+            "config": {"workload": WORKLOADS[args.workload]["name"] + (" [overridden]" if overridden else ""),
+                       "width": W, "height": H, "spp_per_gpu": spp, "spp_total": spp * world, "semantics": "intended" if args.semantics else "literal",
+                       "seeding": "counter", "parallelism": f"spp-split x{world}", "reduce": "rank-ordered gather + add" if args.ordered_reduce else "one sum-reduce to rank 0"},
             "total_mrays_per_s": round((ext_rays + shadow_rays) / dt / 1e6, 2),
             "shadow_mrays_per_s": round(shadow_rays / dt / 1e6, 2),
             "bounces_per_path": round(ext_rays / max(paths, 1), 3),
+            "batch": {"paths": int(st.batch_paths), "path_state_GB": round(st.path_state_bytes / 1e9, 2)},
             "bvh": {"nodes": int(st.bvh_nodes), "max_depth": int(st.bvh_max_depth), "build_ms": round(st.build_ms, 2)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
@@ -199,12 +320,16 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 def cpu_baseline(args, scene):
-    """The CPU oracle on a bounded, strided sample of the same workload."""
+    """The CPU oracle on a bounded, strided sample of the same workload, on every core this job may use."""
     from oracle import oracle_py as orc
-    threads = min(16, os.cpu_count() or 1)
+    nproc = os.cpu_count() or 1
+    # the box exports its per-job CPU share (16 for one GPU) as OMP_NUM_THREADS; nproc counts the whole machine
+    share = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    threads = min(nproc, share) if share > 0 else nproc
     stride, spp = 8, 1
     # grow the sample until it takes a meaningful share of the time budget
     best = None
@@ -225,8 +350,16 @@ def cpu_baseline(args, scene):
         else:
             spp *= 2
     st, stride, spp = best
-    return {"value": round(st.extension_rays / st.seconds / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"every {stride}th pixel in x and y, {spp} spp, same scene and options; {st.extension_rays} extension + {st.shadow_rays} shadow rays in {st.seconds:.1f} s (incl. CPU BVH build)"}
+    return {"value": round(st.extension_rays / st.seconds / 1e6, 3), "unit": "Mrays/s", "cores": threads, "nproc": nproc, "kind": "port",
+            "sample": f"every {stride}th pixel in x and y, {spp} spp, same scene and options; {st.extension_rays} extension + {st.shadow_rays} shadow rays in {st.seconds:.1f} s (incl. CPU BVH build); "
+                      f"{threads} threads = this job's CPU share (OMP_NUM_THREADS) of the machine's {nproc} hardware threads"}
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    sys.exit(run_rank(args))
 
 
 if __name__ == "__main__":

@@ -3,10 +3,20 @@
 The path shards over samples: rank g of G renders the global sample indices
 [g*spp, (g+1)*spp) of EVERY pixel (sample 0, the pixel-centre sample, belongs to
 rank 0 only) with counter-based seeds, into its own pre-gamma radiance sums.  The
-only exchange is one sum-reduce of those W*H*3 floats to rank 0 (RCCL over xGMI on
+only exchange is one combine of those W*H*3 floats on rank 0 (RCCL over xGMI on
 GPUs; gloo in the CPU tests), after which rank 0 averages and gamma-corrects,
 because the reference averages and applies gamma after its sample loop
-(PinholeCamera.cu:70-71)."""
+(PinholeCamera.cu:70-71).
+
+Two ways to combine:
+  * one sum-reduce to rank 0 (default): a single collective; the order in which the
+    ranks' floats are added is the library's, so the last bits may differ from run
+    to run and with the number of ranks;
+  * ordered=True: the ranks' buffers are gathered on rank 0 and added there in rank
+    order, ((s0 + s1) + s2) + ... -- bit-reproducible, and equal bit for bit to
+    rendering the same sample ranges one after the other on one GPU and adding the
+    partial sums in that order.  Costs G buffers on rank 0 (8 x 99.5 MB at 4K).
+"""
 
 
 def sample_range(rank: int, world: int, spp_per_rank: int):
@@ -15,12 +25,27 @@ def sample_range(rank: int, world: int, spp_per_rank: int):
     return rank * spp_per_rank, (rank + 1) * spp_per_rank
 
 
-def split_render_step(renderer, sums, rank: int, world: int, spp_per_rank: int, dist=None):
+def ordered_reduce(sums, rank: int, world: int, dist):
+    """sums (rank 0) <- ((sums_0 + sums_1) + sums_2) + ... in rank order; other ranks keep theirs."""
+    import torch
+    parts = [torch.empty_like(sums) for _ in range(world)] if rank == 0 else None
+    dist.gather(sums, gather_list=parts, dst=0)
+    if rank == 0:
+        acc = parts[0]
+        for p in parts[1:]:
+            acc += p
+        sums.copy_(acc)
+
+
+def split_render_step(renderer, sums, rank: int, world: int, spp_per_rank: int, dist=None, ordered: bool = False):
     """One whole-job render.  `renderer` accumulates into `sums` (a tensor it was
     bound to); `dist` is torch.distributed (needed when world > 1)."""
     j0, j1 = sample_range(rank, world, spp_per_rank)
     renderer.render_range(j0, j1, clear=True)
     if world > 1:
-        dist.reduce(sums, dst=0, op=dist.ReduceOp.SUM)
+        if ordered:
+            ordered_reduce(sums, rank, world, dist)
+        else:
+            dist.reduce(sums, dst=0, op=dist.ReduceOp.SUM)
     if rank == 0:
         renderer.resolve(world * spp_per_rank)
