@@ -1,0 +1,153 @@
+"""The benchmark configurations at their own sizes, and the headline scene against the reference's own
+recorded image -- through the C ABI, against the CPU oracle.
+
+  * dragon.test as shipped (640x480, 128 spp) against images/dragon2.png, the reference's render of it;
+  * the 1920x1080 dragon (the configuration the metric is quoted on): primary hits bit-exact on every
+    8th pixel in x and y, radiance at 2 spp on a window of the full-size frame;
+  * the Cornell box with the GGX sphere exactly as bench.py builds it (cornell_ggx);
+  * the sample-range split (the multi-GPU partition) on the dragon: [0,3) + [3,8) == [0,8) bit for bit;
+  * scene 4/dragonRefract.test (glass triangles in a deep hierarchy), both semantics.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from pathtracer_amd import Renderer, SceneLoader, _ffi, override_scene_text
+from util import ROOT, block_mean, close_fraction, dragon_variant, read_png, scene_text
+
+pytestmark = pytest.mark.gpu
+
+
+def orc():
+    from oracle import oracle_py
+    return oracle_py
+
+
+def bench_module():
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import bench
+    return bench
+
+
+def test_dragon_as_shipped_matches_the_reference_image():
+    """Full size, the scene's own 128 spp, `intended` semantics, reference seeding: 16x16-pixel block
+    means within 2 % relative RMSE of images/dragon2.png (the oracle measures 1.7 % on every other
+    pixel), channel means within 1 %."""
+    scene = SceneLoader().load(os.path.join(ROOT, "scenes", "scene4", "dragon.test"))
+    assert (scene.width, scene.height, scene.samples_per_pixel) == (640, 480, 128)
+    r = Renderer(scene, options={_ffi.OPT_SEMANTICS: 1, _ffi.OPT_SEEDING: 0})
+    r.run()
+    mine = np.frombuffer(bytes(r.getResult()), dtype=np.uint8).reshape(480, 640, 4)[..., :3].astype(np.float64)
+    r.close()
+    ref = read_png(os.path.join(ROOT, "tests", "golden", "ref_dragon2.png"))[..., :3].astype(np.float64)
+    bm, br = block_mean(mine, 16), block_mean(ref, 16)
+    relrmse = np.sqrt(((bm - br) ** 2).mean()) / br.mean()
+    assert relrmse < 0.02, relrmse
+    assert np.allclose(mine.mean(axis=(0, 1)), ref.mean(axis=(0, 1)), rtol=0.01)
+
+
+def test_dragon_1080p_primary_hits_and_window():
+    """BASELINE configs[3] at its own 1920x1080: the hit records of every 8th pixel in x and y are
+    bit-equal to the oracle's; a 2-spp render of the whole frame agrees with the oracle on a
+    320x200 window that covers the dragon's head, the floor and a light reflection."""
+    bench = bench_module()
+    scene = SceneLoader().loadText(bench.scene_text_for("dragon", spp_override=2))
+    assert (scene.width, scene.height) == (1920, 1080)
+    opts = {_ffi.OPT_SEMANTICS: 1, _ffi.OPT_SEEDING: 1}
+    r = Renderer(scene, options=opts)
+    got = r.primary_hits()
+    r.run()
+    gsum = r.sums()
+    st = r.stats()
+    r.close()
+    want = orc().primary_hits(scene, use_bvh=1, stride=8, threads=16)
+    sub = (slice(0, None, 8), slice(0, None, 8))
+    assert (want["prim"][sub] != -2).all()
+    assert (want["prim"][sub] >= 0).mean() > 0.3
+    assert np.array_equal(got["prim"][sub], want["prim"][sub])
+    for f in ("t", "u", "v"):
+        assert np.array_equal(got[f][sub].view(np.uint32), want[f][sub].view(np.uint32)), f
+    x0, y0, x1, y1 = 800, 440, 1120, 640
+    wsum, _, _ = orc().render(scene, semantics=1, seeding=1, use_bvh=1, threads=16, window=(x0, y0, x1, y1))
+    g, w = gsum[y0:y1, x0:x1], wsum[y0:y1, x0:x1]
+    assert (want["prim"][y0:y1:8, x0:x1:8] >= 0).mean() > 0.5   # the window is on the scene
+    assert close_fraction(g, w) >= 0.99
+    bm_g, bm_w = block_mean(g, 8), block_mean(w, 8)
+    assert np.sqrt(((bm_g - bm_w) ** 2).mean()) / np.abs(bm_w).mean() <= 0.02
+    assert st.paths == 1920 * 1080 * 2
+
+
+@pytest.mark.parametrize("seeding", [0, 1])
+@pytest.mark.parametrize("semantics", [0, 1])
+def test_cornell_ggx_sphere_as_benchmarked(semantics, seeding):
+    """The scene bench.py builds for `cornell_ggx` (cornellBRDF.test with `brdf ggx`, roughness 0.25 on
+    the sphere), reduced in size and samples only."""
+    bench = bench_module()
+    text = bench.scene_text_for("cornell_ggx", spp_override=4, size_override="96 96")
+    assert "brdf ggx\nroughness 0.25" in text
+    scene = SceneLoader().loadText(text)
+    assert len(scene.spheres) == 1 and scene.spheres[0].mv.brdf_type == 1 and abs(scene.spheres[0].mv.roughness - 0.25) < 1e-7
+    assert scene.triangles[0].mv.brdf_type == 0  # the walls stay Phong: a mixed scene
+    r = Renderer(scene, options={_ffi.OPT_SEMANTICS: semantics, _ffi.OPT_SEEDING: seeding, _ffi.OPT_BOUNCE_CAP: 12})
+    hits = r.primary_hits()
+    r.run()
+    gsum, st = r.sums(), r.stats()
+    r.close()
+    want_hits = orc().primary_hits(scene)
+    for f in ("prim", "t", "u", "v"):
+        assert np.array_equal(hits[f].view(np.uint32), want_hits[f].view(np.uint32)), f
+    wsum, _, ost = orc().render(scene, semantics=semantics, seeding=seeding, bounce_cap=12)
+    assert st.paths == ost.paths
+    # reference seeding + a sphere: see test_gpu_parity.py::test_pathtracer (dead paths shift the later seeds);
+    # literal GGX: the NaN masks of the two libms differ on a few per cent of the sphere's pixels
+    # (measured: 93.0 % of the pixels at 4 spp with reference seeding, 99.9 % with counter seeding)
+    min_close = 0.90 if seeding == 0 else 0.97 if semantics == 0 else 0.99
+    frac = close_fraction(gsum, wsum)
+    assert frac >= min_close, frac
+    fin = np.isfinite(gsum) & np.isfinite(wsum)
+    bm_g, bm_w = block_mean(np.where(fin, gsum, 0), 8), block_mean(np.where(fin, wsum, 0), 8)
+    assert np.sqrt(((bm_g - bm_w) ** 2).mean()) / max(np.abs(bm_w).mean(), 1e-6) <= 0.03
+
+
+def test_sample_range_partition_is_exact_on_the_dragon():
+    """The multi-GPU partition on the headline scene: samples [0,8) in one go, as [0,3) + [3,8)
+    accumulated, and in small batches -- bit-identical sums (counter seeding)."""
+    scene = SceneLoader().loadText(override_scene_text(scene_text("scene4/dragon.test"), size="320 240", spp="8"))
+    r = Renderer(scene, options={_ffi.OPT_SEMANTICS: 1, _ffi.OPT_SEEDING: 1})
+    r.render_range(0, 8, clear=True)
+    whole = r.sums()
+    r.render_range(0, 3, clear=True)
+    r.render_range(3, 8, clear=False)
+    parts = r.sums()
+    r.set_option(_ffi.OPT_BATCH_PATHS, 320 * 256 * 2)
+    r.render_range(0, 8, clear=True)
+    small = r.sums()
+    r.close()
+    assert np.isfinite(whole).all() and whole.sum() > 0
+    assert np.array_equal(whole.view(np.uint32), parts.view(np.uint32))
+    assert np.array_equal(whole.view(np.uint32), small.view(np.uint32))
+
+
+@pytest.mark.parametrize("semantics", [0, 1])
+def test_dragon_refract(semantics):
+    """scene 4/dragonRefract.test: 100 000 glass triangles (ior 1.0) over the diffuse floor.  A glass hit
+    restarts the path at (0,0,0) with unchanged throughput (RayTracer.cu:517, 935-952)."""
+    scene = SceneLoader().loadText(dragon_variant("refract", size="128 96", spp="2"))
+    r = Renderer(scene, options={_ffi.OPT_SEMANTICS: semantics, _ffi.OPT_SEEDING: 1})
+    hits = r.primary_hits()
+    r.run()
+    gsum, st = r.sums(), r.stats()
+    r.close()
+    want_hits = orc().primary_hits(scene, use_bvh=1)
+    for f in ("prim", "t", "u", "v"):
+        assert np.array_equal(hits[f].view(np.uint32), want_hits[f].view(np.uint32)), f
+    wsum, _, ost = orc().render(scene, semantics=semantics, seeding=1, use_bvh=1)
+    assert st.paths == ost.paths
+    assert close_fraction(gsum, wsum) >= 0.97
+    fin = np.isfinite(gsum) & np.isfinite(wsum)
+    bm_g, bm_w = block_mean(np.where(fin, gsum, 0), 8), block_mean(np.where(fin, wsum, 0), 8)
+    assert np.sqrt(((bm_g - bm_w) ** 2).mean()) / max(np.abs(bm_w).mean(), 1e-6) <= 0.05
+    assert abs(int(st.extension_rays) - int(ost.extension_rays)) <= 0.01 * ost.extension_rays + 16

@@ -98,6 +98,50 @@ def test_intended_semantics_match_reference_images(name, rel, tol):
     assert np.allclose(mine_s.mean(axis=(0, 1)), ref_s.mean(axis=(0, 1)), rtol=0.02)
 
 
+def test_dragon_image_is_matched_by_intended_semantics():
+    """images/dragon2.png is the reference's recorded render of scene 4/dragon.test as shipped (640x480,
+    128 spp, GGX, BRDF sampling, NEE + roulette, maxdepth 5) -- the scene of the headline benchmark.
+    Every fourth pixel in x and y at the scene's own 128 spp: 8x8 blocks of those agree with the image
+    within 3 % relative RMSE and the channel means within 1 % under `intended` semantics (measured at
+    stride 2: 1.7 %, means within 0.4 %); `literal` is 43 % off."""
+    scene = SceneLoader().load(os.path.join(ROOT, "scenes", "scene4", "dragon.test"))
+    assert (scene.width, scene.height, scene.samples_per_pixel) == (640, 480, 128)
+    S = 4
+    h = scene.height
+    top_rows = (h - 1 - np.arange(0, h, S))[::-1]
+    ref_s = read_png(os.path.join(GOLD, "ref_dragon2.png"))[..., :3][top_rows][:, ::S].astype(np.float64)
+    br = block_mean(ref_s, 8)
+    err = {}
+    for sem, spp in ((1, 128), (0, 16)):
+        scene.samples_per_pixel = spp
+        _, res, _ = orc.render(scene, threads=8, semantics=sem, seeding=0, stride=S, use_bvh=1)
+        mine_s = orc.to_rgba8(res)[top_rows][:, ::S, :3].astype(np.float64)
+        err[sem] = np.sqrt(((block_mean(mine_s, 8) - br) ** 2).mean()) / br.mean()
+        if sem == 1:
+            assert np.allclose(mine_s.mean(axis=(0, 1)), ref_s.mean(axis=(0, 1)), rtol=0.01)
+    assert err[1] < 0.03, err
+    assert err[0] > 0.3, err
+
+
+def test_dragon_refract_variant_is_the_shipped_scene():
+    """tests/util.py::dragon_variant("refract") rebuilds scene 4/dragonRefract.test from dragon.test (same
+    geometry; 3.7 MB not kept twice): where the reference tree is present, both parse to the same arrays."""
+    from util import dragon_variant
+    ref = "/root/reference/Scenes/scene 4/dragonRefract.test"
+    if not os.path.exists(ref):
+        pytest.skip("reference tree not present")
+    a = SceneLoader().load(ref)
+    b = SceneLoader().loadText(dragon_variant("refract"))
+    import ctypes as C
+    assert len(a.triangles) == len(b.triangles) == 100006
+    assert C.string_at(a.triangles, C.sizeof(a.triangles)) == C.string_at(b.triangles, C.sizeof(b.triangles))
+    assert C.string_at(a.qlights, C.sizeof(a.qlights)) == C.string_at(b.qlights, C.sizeof(b.qlights))
+    assert bytes(a.config) == bytes(b.config) and a.integratorName == b.integratorName
+    assert (a.samples_per_pixel, a.sampling_method, a.light_samples) == (b.samples_per_pixel, b.sampling_method, b.light_samples)
+    mat = np.frombuffer(a.triangles, dtype=np.int32).reshape(-1, 34)[:, 12 + 16]  # mv.matType: byte 48 + 64
+    assert (mat == 1).sum() == 100000 and (mat == 0).sum() == 6  # the dragon is glass; the 4 light and 2 floor triangles are not
+
+
 def test_literal_semantics_do_not_match_the_readme_image():
     scene = SceneLoader().loadText(override_scene_text(scene_text("scene3/cornellRR.test"), spp="8"))
     _, res, _ = orc.render(scene, threads=8, semantics=0, stride=4, bounce_cap=32)

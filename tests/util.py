@@ -79,10 +79,16 @@ def dragon_variant(kind, **over):
     not worth keeping): "direct" = scene 2/dragon.test (direct integrator, 25 stratified
     samples on each of the 2 quad lights, Phong), "nee" = scene 3/dragon.test (path tracer,
     NEE + Russian roulette, Phong, hemisphere sampling), "raytracer" = scene 1/scene7.test
-    (dragon alone, one point light, the default integrator)."""
+    (dragon alone, one point light, the default integrator), "refract" = scene 4/dragonRefract.test
+    (the dragon as glass with ior 1.0 and a light diffuse colour, the floor explicitly diffuse)."""
     import re
     from pathtracer_amd import override_scene_text
     t = scene_text("scene4/dragon.test")
+    if kind == "refract":
+        t = t.replace("output dragon.png", "output dragonRefract.png", 1)
+        t = t.replace("brdf ggx\ndiffuse 0.08 0.4 0.005\n", "materialtype glass\nior 1.0\n#brdf ggx\ndiffuse 0.88 0.8 0.80\n", 1)
+        t = t.replace("brdf phong\ndiffuse 0.46 0.46 0.46\n", "materialtype diffuse\nior 1.0\nbrdf phong\ndiffuse 0.46 0.46 0.46\n", 1)
+        return override_scene_text(t, **over)
     drop = ["gamma", "importancesampling", "brdf", "roughness"]
     if kind == "raytracer":
         drop += ["integrator", "spp", "nexteventestimation", "russianroulette", "quadLight"]
