@@ -277,6 +277,31 @@ int  ptc_synchronize(ptc_context* ctx);
 int  ptc_collapse_wide(const void* binary_nodes, uint32_t n_nodes, void* wide_nodes_out, uint32_t capacity,
                        uint32_t* n_wide_out, uint32_t* depth_out);
 
+/* ---- build-only test hooks: parts of the path on caller-supplied inputs, so that a divergence from the
+ * CPU restatement can be localised to a function.  Host pointers; synchronous. */
+
+/* One segment of a path: the ray (tmin = Config.epsilon), the payload it carries into the closest-hit
+ * program (throughput, depth, the segment's seed) ... */
+typedef struct PtcSegmentProbe { float o[3], d[3], thr[3]; uint32_t depth, seed; } PtcSegmentProbe;
+/* ... and what comes out of rtTrace + miss / closest-hit program (PinholeCamera.cu:56-66): the segment's
+ * radiance, the payload's throughput / origin / dir / depth afterwards, whether the bounce loop goes on
+ * (!done && depth != maxDepth), and the closest hit itself (global primitive index, -1 = miss; t).
+ * thr, o, d, depth are only defined where alive != 0. */
+typedef struct PtcSegmentResult { float radiance[3], thr[3], o[3], d[3]; uint32_t depth; int32_t alive, prim; float t; } PtcSegmentResult;
+/* Runs extension, surface, shadow and gather kernels once on n caller-made segments with the context's
+ * scene, integrator and options (counter seeding and no zero-throughput cull are forced; the next
+ * segment's seed is not part of the result). */
+int  ptc_probe_segments(ptc_context* ctx, uint32_t n, const PtcSegmentProbe* in, PtcSegmentResult* out);
+/* The device versions of the reference's shading helpers on n inputs of 16 floats each, 4 floats out:
+ *   fn 0 phongBRDF (RayTracer.cu:259-263)   in: wi[3] reflect[3] Kd[3] Ks[3] shininess        out: rgb
+ *   fn 1 ggxBRDF   (:265-285)               in: wi[3] wo[3] n[3] Ks[3] roughness              out: rgb
+ *   fn 2 ggxPDF    (:287-294)               in: wi[3] n[3] h[3] - - - t roughness             out: pdf
+ *   fn 3 Phong-sampled direction (:232-257, 302-322, 675-684, by-reference helpers)
+ *                                           in: w[3] zeta0..2 t shininess sampling_method     out: w_i
+ *   fn 4 GGX-sampled direction (:685-696, by-reference helpers)
+ *                                           in: n[3] wo[3] zeta1 zeta2 roughness              out: w_i */
+int  ptc_eval_shading(ptc_context* ctx, int fn, uint32_t n, const float* in16, float* out4);
+
 int  ptc_set_option(ptc_context* ctx, int option, int64_t value);
 int  ptc_get_stats(ptc_context* ctx, PtcStats* out);
 int  ptc_reset_stats(ptc_context* ctx);

@@ -1269,6 +1269,92 @@ void orc_to_rgba8(const float* result, uint32_t width, uint32_t height, unsigned
         }
 }
 
+// One pass of the bounce loop's body (PinholeCamera.cu:56-66) for caller-made segments.
+int orc_probe_segments(const OrcScene* s, const OrcOptions* o, uint32_t n, const PtcSegmentProbe* in, PtcSegmentResult* out) {
+    int rc = validate(s, o);
+    if (rc) return rc;
+    World w;
+    makeWorld(w, s, o);
+    Counters cnt;
+    Ctx c{&w, &cnt};
+    void (*program)(const Ctx&, const Attributes&, Payload&) =
+        s->integrator == ORC_RAYTRACER ? closestHit : s->integrator == ORC_ANALYTICDIRECT ? analyticDirect : s->integrator == ORC_DIRECT ? direct : s->integrator == ORC_PATHTRACER ? pathTracer : pathTracer2;
+    for (uint32_t i = 0; i < n; ++i) {
+        const PtcSegmentProbe& p = in[i];
+        Payload payload;
+        payload.radiance = f3(.0f);
+        payload.throughput = f3(p.thr[0], p.thr[1], p.thr[2]);
+        payload.depth = p.depth;
+        payload.done = false;
+        payload.seed = p.seed;
+        const F3 origin = f3(p.o[0], p.o[1], p.o[2]), dir = f3(p.d[0], p.d[1], p.d[2]);
+        payload.origin = origin;
+        payload.dir = dir;
+        Ray r{origin, dir, s->config.epsilon, RAY_MAX};
+        Closest hit = traceClosest(w, r);
+        if (hit.prim < 0) {  // Common.cu:13-18
+            payload.radiance = f3(s->background[0], s->background[1], s->background[2]);
+            payload.done = true;
+        } else {
+            Attributes attrib;
+            if ((uint64_t)hit.prim < s->n_tris)
+                triangleAttributes(s->tris[hit.prim], r, hit.t, attrib);
+            else
+                sphereAttributes(s->spheres[hit.prim - s->n_tris], r, attrib);
+            program(c, attrib, payload);
+        }
+        PtcSegmentResult& q = out[i];
+        std::memset(&q, 0, sizeof(q));
+        q.radiance[0] = payload.radiance.x; q.radiance[1] = payload.radiance.y; q.radiance[2] = payload.radiance.z;
+        q.prim = hit.prim;
+        q.t = hit.prim < 0 ? 0.f : hit.t;
+        q.alive = (!payload.done && payload.depth != w.maxDepthEff) ? 1 : 0;
+        if (q.alive) {
+            q.thr[0] = payload.throughput.x; q.thr[1] = payload.throughput.y; q.thr[2] = payload.throughput.z;
+            q.o[0] = payload.origin.x; q.o[1] = payload.origin.y; q.o[2] = payload.origin.z;
+            q.d[0] = payload.dir.x; q.d[1] = payload.dir.y; q.d[2] = payload.dir.z;
+            q.depth = payload.depth;
+        }
+    }
+    return PTC_OK;
+}
+
+// The shading helpers on raw inputs; layouts as for ptc_eval_shading (include/ptcore.h).
+int orc_eval_shading(int fn, uint32_t n, const float* in, float* out) {
+    if (fn < 0 || fn > 4 || !in || !out) return PTC_ERR_INVALID;
+    for (uint32_t i = 0; i < n; ++i) {
+        const float* a = in + 16 * (size_t)i;
+        const F3 v0 = f3(a[0], a[1], a[2]), v1 = f3(a[3], a[4], a[5]), v2 = f3(a[6], a[7], a[8]), v3 = f3(a[9], a[10], a[11]);
+        F3 r = f3(.0f);
+        if (fn == 0) {
+            r = phongBRDF(v0, f3(.0f), v1, a[12], v2, v3);
+        } else if (fn == 1) {
+            r = ggxBRDF(v0, v1, v2, a[12], v3);
+        } else if (fn == 2) {
+            r = f3(ggxPDF(v0, f3(.0f), v1, v2, a[12], a[13]), .0f, .0f);
+        } else if (fn == 3) {  // RayTracer.cu:566, 675-684 with by-reference helpers
+            float theta = .0f, phi = .0f;
+            const float zeta[3] = {a[3], a[4], a[5]};
+            computePolarAngles(1, (uint32_t)a[8], phi, theta, zeta, a[6], a[7]);
+            F3 u = f3(.0f), v = f3(.0f);
+            genCoordFrame(1, v0, u, v);
+            r = sphericalDir(theta, phi, u, v, v0);
+        } else {  // :685-696
+            const float zeta_1 = a[6], zeta_2 = a[7], roughness = a[8];
+            const float theta_h_sample = atanf((roughness * sqrtf(zeta_1)) / sqrtf(1.0f - zeta_1));
+            const float phi_h_sample = 2.0f * PIf * zeta_2;
+            F3 u_h = f3(.0f), v_h = f3(.0f);
+            genCoordFrame(1, v0, u_h, v_h);
+            r = normalize(reflect(-v1, sphericalDir(theta_h_sample, phi_h_sample, u_h, v_h, v0)));
+        }
+        out[4 * (size_t)i] = r.x;
+        out[4 * (size_t)i + 1] = r.y;
+        out[4 * (size_t)i + 2] = r.z;
+        out[4 * (size_t)i + 3] = 0.f;
+    }
+    return PTC_OK;
+}
+
 int orc_primary_hits(const OrcScene* s, const OrcOptions* o, PtcHitRecord* out) {
     int rc = validate(s, o);
     if (rc) return rc;

@@ -70,6 +70,11 @@ int orc_primary_hits(const OrcScene* s, const OrcOptions* o, PtcHitRecord* out);
  * left untouched. */
 int orc_render(const OrcScene* s, const OrcOptions* o, float* sum_out, float* result_out, OrcStats* stats);
 
+/* One pass of the bounce loop's body for n caller-made segments, and the shading helpers on raw
+ * inputs: the CPU side of ptc_probe_segments / ptc_eval_shading (same layouts, include/ptcore.h). */
+int orc_probe_segments(const OrcScene* s, const OrcOptions* o, uint32_t n, const PtcSegmentProbe* in, PtcSegmentResult* out);
+int orc_eval_shading(int fn, uint32_t n, const float* in16, float* out4);
+
 /* Known-answer helpers for the RNG (random.h:31-67). */
 uint32_t orc_tea16(uint32_t v0, uint32_t v1);
 uint32_t orc_lcg(uint32_t* state);

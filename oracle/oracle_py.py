@@ -66,6 +66,8 @@ def lib():
         l.orc_fresnel_schlick.restype = C.c_float
         l.orc_phase_hg.argtypes = [C.c_float, C.c_float]
         l.orc_phase_hg.restype = C.c_float
+        l.orc_probe_segments.argtypes = [C.POINTER(OrcScene), C.POINTER(OrcOptions), C.c_uint32, C.c_void_p, C.c_void_p]
+        l.orc_eval_shading.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
         _lib = l
     return _lib
 
@@ -138,3 +140,22 @@ def refract(i, n, ior):
     r = np.zeros(3, dtype=np.float32)
     ok = lib().orc_refract(i.ctypes.data, n.ctypes.data, ior, r.ctypes.data)
     return bool(ok), r
+
+
+def probe_segments(scene, probes: np.ndarray, **opts) -> np.ndarray:
+    """One closest-hit program invocation per caller-made segment (dtype _ffi.PROBE_IN -> _ffi.PROBE_OUT)."""
+    s, o = make_scene(scene), make_options(**opts)
+    probes = np.ascontiguousarray(probes, dtype=_ffi.PROBE_IN)
+    out = np.zeros(len(probes), dtype=_ffi.PROBE_OUT)
+    rc = lib().orc_probe_segments(C.byref(s), C.byref(o), len(probes), probes.ctypes.data, out.ctypes.data)
+    if rc:
+        raise RuntimeError(lib().orc_last_error().decode())
+    return out
+
+
+def eval_shading(fn: int, inputs: np.ndarray) -> np.ndarray:
+    inputs = np.ascontiguousarray(inputs, dtype=np.float32).reshape(-1, 16)
+    out = np.zeros((len(inputs), 4), dtype=np.float32)
+    if lib().orc_eval_shading(fn, len(inputs), inputs.ctypes.data, out.ctypes.data):
+        raise RuntimeError("orc_eval_shading: bad argument")
+    return out

@@ -84,6 +84,12 @@ class SceneView(C.Structure):
 assert C.sizeof(MaterialValue) == 84 and C.sizeof(Triangle) == 136 and C.sizeof(Sphere) == 152
 assert C.sizeof(QuadLight) == 284 and C.sizeof(Config) == 88 and C.sizeof(HitRecord) == 16
 
+# PtcSegmentProbe / PtcSegmentResult as numpy record types
+import numpy as _np  # noqa: E402
+PROBE_IN = _np.dtype([("o", "<f4", 3), ("d", "<f4", 3), ("thr", "<f4", 3), ("depth", "<u4"), ("seed", "<u4")])
+PROBE_OUT = _np.dtype([("radiance", "<f4", 3), ("thr", "<f4", 3), ("o", "<f4", 3), ("d", "<f4", 3), ("depth", "<u4"), ("alive", "<i4"), ("prim", "<i4"), ("t", "<f4")])
+assert PROBE_IN.itemsize == 44 and PROBE_OUT.itemsize == 64
+
 # option ids (include/ptcore.h)
 OPT_SEMANTICS, OPT_SEEDING, OPT_BOUNCE_CAP, OPT_CULL_ZERO = 1, 2, 3, 4
 OPT_BATCH_PATHS, OPT_PROFILE, OPT_COUNT_TRAVERSAL, OPT_BRUTE_FORCE = 5, 6, 7, 8
@@ -124,7 +130,7 @@ CORE_SYMBOLS = [
     "ptc_set_triangles", "ptc_set_spheres", "ptc_set_lights", "ptc_set_background", "ptc_build", "ptc_render",
     "ptc_render_range", "ptc_resolve", "ptc_primary_hits", "ptc_read_result", "ptc_read_sum",
     "ptc_bind_sum_buffer", "ptc_set_stream", "ptc_synchronize", "ptc_set_option", "ptc_get_stats", "ptc_reset_stats",
-    "ptc_collapse_wide", "ptc_render_range_static",
+    "ptc_collapse_wide", "ptc_render_range_static", "ptc_probe_segments", "ptc_eval_shading",
 ]
 
 
@@ -155,6 +161,8 @@ def core_lib():
         lib.ptc_render.argtypes = [vp, C.c_int, u32, u32]
         lib.ptc_render_range.argtypes = [vp, C.c_int, u32, u32, i32, i32, C.c_int]
         lib.ptc_render_range_static.argtypes = [vp, C.c_int, u32, u32, i32, i32, C.c_int, vp, C.c_size_t]
+        lib.ptc_probe_segments.argtypes = [vp, u32, vp, vp]
+        lib.ptc_eval_shading.argtypes = [vp, C.c_int, u32, vp, vp]
         lib.ptc_resolve.argtypes = [vp, C.c_int, i32]
         lib.ptc_primary_hits.argtypes = [vp, u32, u32, vp]
         lib.ptc_read_result.argtypes = [vp, vp]

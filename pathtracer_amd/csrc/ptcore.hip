@@ -380,19 +380,20 @@ int uploadLights(ptc_context* ctx) {
 // survivors -> next queue), shadow, gather (radiance of the segments that sampled the lights).  Queue
 // lengths stay on the device; the grids are sized by the bounce's path count; the next
 // queue's length is the one word read back.
-int runBounces(ptc_context* ctx, const RenderParams& rp, const DevScene& sc, uint32_t count0, uint32_t sample_begin) {
+int runBounces(ptc_context* ctx, const RenderParams& rp, const DevScene& sc, uint32_t count0, uint32_t sample_begin, uint32_t max_iters = 0xFFFFFFFFu,
+               uint32_t* survivors = nullptr, bool first_is_camera = true) {
     uint32_t count = count0;
     uint32_t bounce = 0;
     const uint32_t S = rp.samples_per_path;
     // k_gather only adds to L; hit compaction does too when there is a background colour
     const bool overlap = ctx->overlap_gather && !(rp.bg[0] != 0.f || rp.bg[1] != 0.f || rp.bg[2] != 0.f);
     bool gather_pending = false;
-    while (count > 0) {
+    while (count > 0 && bounce < max_iters) {
         uint32_t* grp = ctx->qcount + 8 * (bounce & 1u);  // {hit count, next count, shadow-ray count, extend work, shadow work, gather count}
         CHK(hipMemsetAsync(grp, 0, 6 * sizeof(uint32_t), ctx->stream));
         {
             Timed t(ctx, 0);
-            wf_extend(ctx->stream, rp, sc, ctx->ps, count, grp + 3, ctx->resident_waves, bounce == 0, ctx->count_trav != 0, ctx->counters);
+            wf_extend(ctx->stream, rp, sc, ctx->ps, count, grp + 3, ctx->resident_waves, bounce == 0 && first_is_camera, ctx->count_trav != 0, ctx->counters);
         }
         ctx->stats.extension_rays += count;
         ctx->stats.extend_launches++;
@@ -407,7 +408,7 @@ int runBounces(ptc_context* ctx, const RenderParams& rp, const DevScene& sc, uin
         {
             Timed t(ctx, 2);
             wf_surface(ctx->stream, rp, sc, ctx->ps, ctx->hitq, grp, count, ctx->npix_pad, sample_begin, ctx->segctr, grp + 1, ctx->gatherq,
-                       grp + 5, grp + 2, bounce == 0);
+                       grp + 5, grp + 2, bounce == 0 && first_is_camera);
         }
         if (S) {
             {
@@ -442,6 +443,7 @@ int runBounces(ptc_context* ctx, const RenderParams& rp, const DevScene& sc, uin
         ++bounce;
     }
     if (gather_pending) CHK(hipStreamWaitEvent(ctx->stream, ctx->ev_gather, 0));
+    if (survivors) *survivors = count;
     return PTC_OK;
 }
 
@@ -909,6 +911,109 @@ int ptc_set_stream(ptc_context* ctx, void* hip_stream) {
 int ptc_synchronize(ptc_context* ctx) {
     ENTER();
     CHK(hipStreamSynchronize(ctx->stream));
+    return PTC_OK;
+}
+
+int ptc_probe_segments(ptc_context* ctx, uint32_t n, const PtcSegmentProbe* in, PtcSegmentResult* out) {
+    ENTER();
+    if (n == 0) return PTC_OK;
+    if (!in || !out) return fail(ctx, PTC_ERR_INVALID, "null probe array");
+    if (n > (1u << 24)) return fail(ctx, PTC_ERR_INVALID, "at most 2^24 probes");
+    RenderParams rp;
+    int rc = makeParams(ctx, 1, 64, 64, rp);  // the image size only enters the NEXT segment's seed, which is not reported
+    if (rc) return rc;
+    rp.seeding = 1;  // leaves the per-pixel segment counters alone
+    rp.cull_zero = 0;
+    rp.bounce_cap = 0xFFFFFFFFu;
+    const uint32_t S = rp.samples_per_path;
+    const uint32_t cap = (n + 4095u) & ~4095u;
+    rc = ensureTargets(ctx, ctx->width ? ctx->width : 64, ctx->height ? ctx->height : 64);  // segctr / acc exist
+    if (rc) return rc;
+    rc = ensurePaths(ctx, cap, S);
+    if (rc) return rc;
+    std::vector<float4> o(n), d(n), t(n), L(n, make_float4(0.f, 0.f, 0.f, 0.f));
+    std::vector<uint32_t> pid(n);
+    auto bits = [](uint32_t u) {
+        float f;
+        std::memcpy(&f, &u, 4);
+        return f;
+    };
+    for (uint32_t i = 0; i < n; ++i) {
+        o[i] = make_float4(in[i].o[0], in[i].o[1], in[i].o[2], bits(in[i].seed));
+        d[i] = make_float4(in[i].d[0], in[i].d[1], in[i].d[2], bits(in[i].depth));
+        t[i] = make_float4(in[i].thr[0], in[i].thr[1], in[i].thr[2], bits(in[i].depth));  // segment number = depth
+        pid[i] = i;
+    }
+    hipStream_t s = ctx->stream;
+    CHK(hipMemcpyAsync(ctx->ps.o_seed, o.data(), n * sizeof(float4), hipMemcpyHostToDevice, s));
+    CHK(hipMemcpyAsync(ctx->ps.d_depth, d.data(), n * sizeof(float4), hipMemcpyHostToDevice, s));
+    CHK(hipMemcpyAsync(ctx->ps.thr, t.data(), n * sizeof(float4), hipMemcpyHostToDevice, s));
+    CHK(hipMemcpyAsync(ctx->ps.pid, pid.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    CHK(hipMemcpyAsync(ctx->ps.L, L.data(), n * sizeof(float4), hipMemcpyHostToDevice, s));
+    CHK(hipStreamSynchronize(s));
+    const DevScene sc = deviceScene(ctx);
+    void* tmp = nullptr;
+    CHK(hipMalloc(&tmp, (size_t)n * 8));
+    uint32_t alive_n = 0;
+    const PtcStats saved = ctx->stats;
+    rc = runBounces(ctx, rp, sc, n, 0u, 1u, &alive_n, false);
+    ctx->stats = saved;  // probes are not part of the render statistics
+    if (rc) {
+        (void)hipFree(tmp);
+        return rc;
+    }
+    // hit_t / hit_ref are indexed by the position of the segment, which is the probe number here
+    wf_probe_hits(s, sc, ctx->ps, n, (int32_t*)tmp, (float*)tmp + n);
+    std::vector<int32_t> prim(n);
+    std::vector<float> ht(n);
+    CHK(hipMemcpyAsync(prim.data(), tmp, n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    CHK(hipMemcpyAsync(ht.data(), (float*)tmp + n, n * sizeof(float), hipMemcpyDeviceToHost, s));
+    CHK(hipMemcpyAsync(L.data(), ctx->ps.L, n * sizeof(float4), hipMemcpyDeviceToHost, s));
+    if (alive_n) {  // runBounces swapped the arrays: the survivors are the current state
+        CHK(hipMemcpyAsync(o.data(), ctx->ps.o_seed, alive_n * sizeof(float4), hipMemcpyDeviceToHost, s));
+        CHK(hipMemcpyAsync(d.data(), ctx->ps.d_depth, alive_n * sizeof(float4), hipMemcpyDeviceToHost, s));
+        CHK(hipMemcpyAsync(t.data(), ctx->ps.thr, alive_n * sizeof(float4), hipMemcpyDeviceToHost, s));
+        CHK(hipMemcpyAsync(pid.data(), ctx->ps.pid, alive_n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    }
+    CHK(hipStreamSynchronize(s));
+    (void)hipFree(tmp);
+    CHK(hipGetLastError());
+    for (uint32_t i = 0; i < n; ++i) {
+        std::memset(&out[i], 0, sizeof(out[i]));
+        out[i].radiance[0] = L[i].x;
+        out[i].radiance[1] = L[i].y;
+        out[i].radiance[2] = L[i].z;
+        out[i].prim = prim[i];
+        out[i].t = ht[i];
+    }
+    for (uint32_t k = 0; k < alive_n; ++k) {
+        if (pid[k] >= n) return fail(ctx, PTC_ERR_DEVICE, "probe: survivor with a bad path number");
+        PtcSegmentResult& r = out[pid[k]];
+        r.alive = 1;
+        r.o[0] = o[k].x; r.o[1] = o[k].y; r.o[2] = o[k].z;
+        r.d[0] = d[k].x; r.d[1] = d[k].y; r.d[2] = d[k].z;
+        r.thr[0] = t[k].x; r.thr[1] = t[k].y; r.thr[2] = t[k].z;
+        std::memcpy(&r.depth, &d[k].w, 4);
+    }
+    return PTC_OK;
+}
+
+int ptc_eval_shading(ptc_context* ctx, int fn, uint32_t n, const float* in16, float* out4) {
+    ENTER();
+    if (n == 0) return PTC_OK;
+    if (!in16 || !out4 || fn < 0 || fn > 4) return fail(ctx, PTC_ERR_INVALID, "bad argument");
+    float *d_in = nullptr, *d_out = nullptr;
+    CHK(hipMalloc((void**)&d_in, (size_t)n * 16 * sizeof(float)));
+    hipError_t e = hipMalloc((void**)&d_out, (size_t)n * 4 * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in, in16, (size_t)n * 16 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        wf_eval_shading(ctx->stream, fn, n, d_in, d_out);
+        e = hipMemcpyAsync(out4, d_out, (size_t)n * 4 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(ctx, PTC_ERR_DEVICE, std::string("ptc_eval_shading: ") + hipGetErrorString(e));
     return PTC_OK;
 }
 

@@ -34,6 +34,10 @@ void wf_accumulate(hipStream_t s, const RenderParams& rp, const PathState& ps, u
 void wf_resolve(hipStream_t s, const float* acc, float* result, uint32_t n_pixels, int spp, float gamma, int frame_id);
 void wf_hit_records(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, uint32_t count, PtcHitRecord* out);
 
+// test hooks: closest hits of entries [0, count) as (global primitive index, t); the shading helpers on raw inputs
+void wf_probe_hits(hipStream_t s, const DevScene& sc, const PathState& ps, uint32_t count, int32_t* prim, float* t);
+void wf_eval_shading(hipStream_t s, int fn, uint32_t n, const float* in, float* out);
+
 // ---- BVH build (bvh_build.hip) ----------------------------------------------
 struct BvhBuildInput {
     const PtcTriangle* d_tris;   // device copies of the AoS uploads

@@ -1492,6 +1492,49 @@ __global__ __launch_bounds__(BLOCK) void k_hit_records(RenderParams rp, DevScene
     out[(size_t)y * rp.width + x] = rec;
 }
 
+// ------------------------------------------------------------- test hooks --
+// Global primitive index and distance of the closest hits of entries [0, count) (probe order).
+__global__ __launch_bounds__(BLOCK) void k_probe_hits(DevScene sc, PathState ps, uint32_t count, int32_t* __restrict__ prim, float* __restrict__ t) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= count) return;
+    const int ref = ps.hit_ref[i];
+    prim[i] = ref == HIT_MISS ? -1 : ref >= 0 ? sc.tri_prim[ref] : sc.sph_prim[HIT_SPHERE_SLOT(ref)];
+    t[i] = ref == HIT_MISS ? 0.f : ps.hit_t[i];
+}
+
+// The shading helpers on caller-made inputs (16 floats in, 4 out per item); see ptc_eval_shading.
+__global__ __launch_bounds__(BLOCK) void k_eval_shading(int fn, uint32_t n, const float* __restrict__ in, float* __restrict__ out) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float* a = in + 16 * (size_t)i;
+    const vec3 v0 = mk3(a[0], a[1], a[2]), v1 = mk3(a[3], a[4], a[5]), v2 = mk3(a[6], a[7], a[8]), v3 = mk3(a[9], a[10], a[11]);
+    vec3 r = mk3(0.f);
+    if (fn == 0) {
+        r = phong_brdf(v0, v1, a[12], v2, v3);
+    } else if (fn == 1) {
+        r = ggx_brdf(v0, v1, v2, a[12], v3);
+    } else if (fn == 2) {
+        r = mk3(ggx_pdf(v0, v1, v2, a[12], a[13]), 0.f, 0.f);
+    } else if (fn == 3) {
+        PolarAngle theta = angle_zero();
+        float phi = 0.f;
+        compute_polar_angles(1, (uint32_t)a[8], phi, theta, a[3], a[4], a[5], a[6], a[7]);
+        vec3 u = mk3(0.f), v = mk3(0.f);
+        gen_coord_frame(1, v0, u, v);
+        r = spherical_dir(theta, phi, u, v, v0);
+    } else if (fn == 4) {
+        const float zeta_1 = a[6], zeta_2 = a[7], roughness = a[8];
+        const PolarAngle theta_h = angle_atan((roughness * sqrtf(zeta_1)) / sqrtf(1.0f - zeta_1), false);
+        vec3 u = mk3(0.f), v = mk3(0.f);
+        gen_coord_frame(1, v0, u, v);
+        r = normalize(reflect(-v1, spherical_dir(theta_h, zeta_2, u, v, v0)));
+    }
+    out[4 * (size_t)i] = r.x;
+    out[4 * (size_t)i + 1] = r.y;
+    out[4 * (size_t)i + 2] = r.z;
+    out[4 * (size_t)i + 3] = 0.f;
+}
+
 // --------------------------------------------------------------- launchers --
 static inline uint32_t blocks_for(uint64_t n, uint32_t block = BLOCK) { return (uint32_t)((n + block - 1) / block); }
 
@@ -1653,6 +1696,16 @@ void wf_accumulate(hipStream_t s, const RenderParams& rp, const PathState& ps, u
 
 void wf_resolve(hipStream_t s, const float* acc, float* result, uint32_t n_pixels, int spp, float gamma, int frame_id) {
     hipLaunchKernelGGL(k_resolve, dim3(blocks_for(n_pixels)), dim3(BLOCK), 0, s, acc, result, n_pixels, spp, gamma, frame_id);
+}
+
+void wf_probe_hits(hipStream_t s, const DevScene& sc, const PathState& ps, uint32_t count, int32_t* prim, float* t) {
+    if (count == 0) return;
+    hipLaunchKernelGGL(k_probe_hits, dim3(blocks_for(count)), dim3(BLOCK), 0, s, sc, ps, count, prim, t);
+}
+
+void wf_eval_shading(hipStream_t s, int fn, uint32_t n, const float* in, float* out) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_eval_shading, dim3(blocks_for(n)), dim3(BLOCK), 0, s, fn, n, in, out);
 }
 
 void wf_hit_records(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, uint32_t count, PtcHitRecord* out) {

@@ -121,6 +121,20 @@ class Renderer:
         self._check(self._lib.ptc_primary_hits(self._ctx, self.width, self.height, rec.ctypes.data))
         return rec
 
+    def probe_segments(self, probes: np.ndarray) -> np.ndarray:
+        """ptc_probe_segments: one extension + closest-hit program per caller-made segment."""
+        probes = np.ascontiguousarray(probes, dtype=_ffi.PROBE_IN)
+        out = np.zeros(len(probes), dtype=_ffi.PROBE_OUT)
+        self._check(self._lib.ptc_probe_segments(self._ctx, len(probes), probes.ctypes.data, out.ctypes.data))
+        return out
+
+    def eval_shading(self, fn: int, inputs: np.ndarray) -> np.ndarray:
+        """ptc_eval_shading: the device shading helpers on raw inputs, (n, 16) floats -> (n, 4)."""
+        inputs = np.ascontiguousarray(inputs, dtype=np.float32).reshape(-1, 16)
+        out = np.zeros((len(inputs), 4), dtype=np.float32)
+        self._check(self._lib.ptc_eval_shading(self._ctx, fn, len(inputs), inputs.ctypes.data, out.ctypes.data))
+        return out
+
     def stats(self) -> _ffi.Stats:
         st = _ffi.Stats()
         self._check(self._lib.ptc_get_stats(self._ctx, C.byref(st)))
