@@ -517,7 +517,89 @@ std::string plocBuild(hipStream_t s, const Box6* d_boxes, const uint32_t* d_sort
     return "";
 }
 
-// Tree over the small primitives of one kind (builder 0: LBVH, 1: PLOC); writes the emitted nodes to nodes[node_base..].
+// Top-down surface-area-heuristic build on the host (builder 2): every node is split where the sweep over
+// the primitives sorted by centroid, along the best of the three axes, minimises
+// area(left) * count(left) + area(right) * count(right).  Same output format as plocBuild: leaves 0..n-1
+// (positions in `prims`), internal nodes n..2n-2, boxes padded.  O(n log^2 n), single-threaded: the
+// better-quality / slower-build end of the builder choice.
+void sahBuild(const std::vector<Box6>& boxes, const std::vector<uint32_t>& prims, float pad, std::vector<int>& left, std::vector<int>& right,
+              std::vector<Box6>& box, int& root) {
+    const int n = (int)prims.size();
+    left.assign(n - 1, -1);
+    right.assign(n - 1, -1);
+    box.assign(2 * (size_t)n - 1, emptyBox());
+    std::vector<float> cen[3];
+    for (int k = 0; k < 3; ++k) cen[k].resize(n);
+    for (int i = 0; i < n; ++i) {
+        Box6 b = boxes[prims[i]];
+        for (int k = 0; k < 3; ++k) {
+            cen[k][i] = 0.5f * (b.lo[k] + b.hi[k]);
+            b.lo[k] -= pad;
+            b.hi[k] += pad;
+        }
+        box[i] = b;
+    }
+    std::vector<int> idx(n), tmp(n);
+    for (int i = 0; i < n; ++i) idx[i] = i;
+    std::vector<float> suffix(n + 1);
+    struct Job {
+        int first, count, node;  // idx[first, first+count) -> internal node `node` (n-based)
+    };
+    int next_internal = n;
+    root = next_internal++;
+    std::vector<Job> jobs{{0, n, root}};
+    auto area = [](const Box6& b) {
+        const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    while (!jobs.empty()) {
+        const Job j = jobs.back();
+        jobs.pop_back();
+        int* a = idx.data() + j.first;
+        Box6 nb = emptyBox();
+        for (int i = 0; i < j.count; ++i) grow(nb, box[a[i]]);
+        box[j.node] = nb;
+        int best_axis = -1, best_split = j.count / 2;
+        float best_cost = INFINITY;
+        for (int k = 0; k < 3 && j.count > 2; ++k) {
+            std::copy(a, a + j.count, tmp.begin());
+            std::sort(tmp.begin(), tmp.begin() + j.count, [&](int x, int y) { return cen[k][x] < cen[k][y] || (cen[k][x] == cen[k][y] && x < y); });
+            Box6 acc = emptyBox();
+            suffix[j.count] = 0.f;
+            for (int i = j.count - 1; i > 0; --i) {
+                grow(acc, box[tmp[i]]);
+                suffix[i] = area(acc);
+            }
+            acc = emptyBox();
+            for (int i = 1; i < j.count; ++i) {
+                grow(acc, box[tmp[i - 1]]);
+                const float cost = area(acc) * (float)i + suffix[i] * (float)(j.count - i);
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    best_axis = k;
+                    best_split = i;
+                }
+            }
+        }
+        if (best_axis >= 0)
+            std::sort(a, a + j.count, [&](int x, int y) { return cen[best_axis][x] < cen[best_axis][y] || (cen[best_axis][x] == cen[best_axis][y] && x < y); });
+        const int nl = best_split, nr = j.count - best_split;
+        int child[2];
+        const int firsts[2] = {j.first, j.first + nl}, counts[2] = {nl, nr};
+        for (int c = 0; c < 2; ++c) {
+            if (counts[c] == 1) {
+                child[c] = idx[firsts[c]];
+            } else {
+                child[c] = next_internal++;
+                jobs.push_back({firsts[c], counts[c], child[c]});
+            }
+        }
+        left[j.node - n] = child[0];
+        right[j.node - n] = child[1];
+    }
+}
+
+// Tree over the small primitives of one kind (builder 0: LBVH, 1: PLOC, 2: host SAH sweep); writes the emitted nodes to nodes[node_base..].
 std::string buildKind(hipStream_t s, const Box6* d_boxes, const std::vector<Box6>& boxes, uint32_t kind, float pad, int builder, BvhNode* d_nodes,
                       uint32_t node_base, KindResult& res) {
     std::vector<uint32_t> small, big;
@@ -543,6 +625,24 @@ std::string buildKind(hipStream_t s, const Box6* d_boxes, const std::vector<Box6
             Box6 c;
             for (int k = 0; k < 3; ++k) c.lo[k] = c.hi[k] = 0.5f * (boxes[i].lo[k] + boxes[i].hi[k]);
             grow(cb, c);
+        }
+        if (builder == 2) {
+            std::vector<int> h_left, h_right, order;
+            std::vector<Box6> h_box;
+            std::vector<BvhNode> h_nodes;
+            int root = 0;
+            sahBuild(boxes, small, pad, h_left, h_right, h_box, root);
+            uint32_t depth = 0;
+            emitTree(h_left, h_right, h_box, n, root, kind, node_base, h_nodes, order, depth);
+            HIPCHK(hipMemcpyAsync(d_nodes + node_base, h_nodes.data(), sizeof(BvhNode) * h_nodes.size(), hipMemcpyHostToDevice, s));
+            HIPCHK(hipStreamSynchronize(s));
+            res.max_depth = depth;
+            res.n_tree_nodes = (uint32_t)h_nodes.size();
+            res.has_tree = true;
+            res.tree_box = h_box[root];
+            for (int i = 0; i < n; ++i) res.slot_prim.push_back((int32_t)small[order[i]]);
+            for (uint32_t i : big) res.slot_prim.push_back((int32_t)i);
+            return "";
         }
         float3 cmin = make_float3(cb.lo[0], cb.lo[1], cb.lo[2]);
         float3 cinv;

@@ -1043,7 +1043,7 @@ int ptc_set_option(ptc_context* ctx, int option, int64_t value) {
         case PTC_OPT_GROUP_HITS: ctx->group_hits = value != 0; break;
         case PTC_OPT_OVERLAP_GATHER: ctx->overlap_gather = value != 0; break;
         case PTC_OPT_BVH_BUILDER:
-            if (value != 0 && value != 1) return fail(ctx, PTC_ERR_INVALID, "BVH builder must be 0 (LBVH) or 1 (PLOC)");
+            if (value < 0 || value > 2) return fail(ctx, PTC_ERR_INVALID, "BVH builder must be 0 (LBVH), 1 (PLOC) or 2 (SAH sweep on the host)");
             ctx->bvh_builder = (int)value;
             ctx->built = false;
             break;
