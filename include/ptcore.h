@@ -305,6 +305,12 @@ int  ptc_probe_segments(ptc_context* ctx, uint32_t n, const PtcSegmentProbe* in,
  *                                           in: n[3] wo[3] zeta1 zeta2 roughness              out: w_i */
 int  ptc_eval_shading(ptc_context* ctx, int fn, uint32_t n, const float* in16, float* out4);
 
+/* The raw device counters of the PTC_OPT_COUNT_TRAVERSAL instantiations since the last ptc_reset_stats
+ * (up to 24 words): [0..3] nodes visited / primitives tested by extension and shadow rays, [4] shadow rays,
+ * [8..14] extension and [16..22] shadow rays in the kernel with deferred tests, per wave summed over the
+ * launch: loop iterations; lanes owning a ray, visiting a node, standing at a leaf in them; full batches of
+ * 64 tests; partial batches and the tests in them. */
+int  ptc_debug_counters(ptc_context* ctx, uint64_t* out, uint32_t n);
 int  ptc_set_option(ptc_context* ctx, int option, int64_t value);
 int  ptc_get_stats(ptc_context* ctx, PtcStats* out);
 int  ptc_reset_stats(ptc_context* ctx);

@@ -372,7 +372,7 @@ int uploadLights(ptc_context* ctx) {
     return PTC_OK;
 }
 
-#define N_COUNTERS 8
+#define N_COUNTERS 24  /* [0..3] nodes / primitives (extension, shadow), [4] shadow rays, [5..6] maxima, [8..14] / [16..22] schedule statistics of the deferred kernel */
 #define N_QCOUNT 20
 
 // Trace every bounce of the count0 paths k_generate left in the path state.  Per bounce:
@@ -1062,6 +1062,14 @@ int ptc_collapse_wide(const void* binary_nodes, uint32_t n_nodes, void* wide_nod
     if (!binary_nodes || !wide_nodes_out || !n_wide_out || !depth_out || n_nodes == 0) return PTC_ERR_INVALID;
     const int rc = bvh_collapse_wide_host((const BvhNode*)binary_nodes, n_nodes, (WideNode*)wide_nodes_out, capacity, n_wide_out, depth_out);
     return rc == 0 ? PTC_OK : rc == 1 ? PTC_ERR_UNSUPPORTED : PTC_ERR_INVALID;  // 2 = capacity, 3 = malformed nodes
+}
+
+int ptc_debug_counters(ptc_context* ctx, uint64_t* out, uint32_t n) {
+    ENTER();
+    if (!out || n > N_COUNTERS) return fail(ctx, PTC_ERR_INVALID, "bad argument");
+    CHK(hipStreamSynchronize(ctx->stream));
+    CHK(hipMemcpy(out, ctx->counters, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return PTC_OK;
 }
 
 int ptc_get_stats(ptc_context* ctx, PtcStats* out) {

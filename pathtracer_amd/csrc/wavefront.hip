@@ -503,6 +503,9 @@ __global__ __launch_bounds__(BLOCK, DQ_MIN_WAVES) void k_trace_deferred(RenderPa
     bool active = false;                     // this lane owns a ray
     WaveWork w = {0u, 0u, false};
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    // COUNT only, wave-uniform: loop iterations, lanes that own a ray / visit a node / are at a leaf in them,
+    // full and partial batches of primitive tests, items in the partial ones
+    uint32_t st_iters = 0, st_owned = 0, st_node = 0, st_leaf = 0, st_full = 0, st_part = 0, st_part_items = 0;
     for (;;) {
         // ---- retire finished rays, fetch new ones
         const bool fin = active && cur == REF_DONE;
@@ -513,6 +516,13 @@ __global__ __launch_bounds__(BLOCK, DQ_MIN_WAVES) void k_trace_deferred(RenderPa
             wave_lds_sync();
             while (qn > 0u) {
                 const uint32_t n = qn < 64u ? qn : 64u;
+                if (COUNT) {
+                    if (n == 64u) st_full++;
+                    else {
+                        st_part++;
+                        st_part_items += n;
+                    }
+                }
                 if (lane < n) {
                     if (COUNT) cnt.prims++;
                     deferred_item<ANY>(sc, L, items[qn - n + lane], wave_base, rp.cf.epsilon);
@@ -583,11 +593,19 @@ __global__ __launch_bounds__(BLOCK, DQ_MIN_WAVES) void k_trace_deferred(RenderPa
         if (qn >= 64u) {
             wave_lds_sync();
             do {
-                if (COUNT) cnt.prims++;
+                if (COUNT) {
+                    cnt.prims++;
+                    st_full++;
+                }
                 deferred_item<ANY>(sc, L, items[qn - 64u + lane], wave_base, rp.cf.epsilon);
                 qn -= 64u;
             } while (qn >= 64u);
             wave_lds_sync();
+        }
+        if (COUNT) {
+            st_iters++;
+            st_owned += (uint32_t)__popcll(__ballot(active));
+            st_node += (uint32_t)__popcll(__ballot(do_node));
         }
         // ---- ... then descend (the closest distance includes the tests just made)
         if (do_node) {
@@ -604,6 +622,7 @@ __global__ __launch_bounds__(BLOCK, DQ_MIN_WAVES) void k_trace_deferred(RenderPa
         // ---- leaves: queue their primitives, carry on with the stack
         const uint32_t kind = REF_KIND(cur);
         const bool leaf = active && cur != REF_DONE && (kind == REF_TRI || kind == REF_SPHERE);
+        if (COUNT) st_leaf += (uint32_t)__popcll(__ballot(leaf));
         if (__any(leaf)) {
             const uint32_t have = leaf ? REF_COUNT(cur) : 0u;
             const uint32_t n = have < DQ_LEAF ? have : DQ_LEAF;  // 0..4
@@ -626,6 +645,16 @@ __global__ __launch_bounds__(BLOCK, DQ_MIN_WAVES) void k_trace_deferred(RenderPa
     if (COUNT) {
         atomicAdd(&trav_counters[ANY ? 2 : 0], (unsigned long long)cnt.nodes);
         atomicAdd(&trav_counters[ANY ? 3 : 1], (unsigned long long)cnt.prims);
+        if (lane == 0) {
+            unsigned long long* st = trav_counters + (ANY ? 16 : 8);
+            atomicAdd(&st[0], (unsigned long long)st_iters);
+            atomicAdd(&st[1], (unsigned long long)st_owned);
+            atomicAdd(&st[2], (unsigned long long)st_node);
+            atomicAdd(&st[3], (unsigned long long)st_leaf);
+            atomicAdd(&st[4], (unsigned long long)st_full);
+            atomicAdd(&st[5], (unsigned long long)st_part);
+            atomicAdd(&st[6], (unsigned long long)st_part_items);
+        }
     }
 }
 

@@ -19,3 +19,13 @@ def root():
 
 def scene_path(*parts):
     return os.path.join(ROOT, "scenes", *parts)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _torch_device_first():
+    """Where a GPU is present, bring torch's HIP context up before the first context of libptcore.so:
+    the order bench.py uses.  (Without a GPU this is a no-op.)"""
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.init()
+    yield
