@@ -168,7 +168,7 @@ enum {
      * 4 = refilling waves with deferred primitive tests (leaf primitives go to a
      * per-wave queue in LDS and are tested 64 at a time) over the two-child nodes,
      * 6 = the same over the four-wide nodes with 8-bit child boxes, 5 = automatic: 0 for
-     * hierarchies of at most 64 nodes, 6 otherwise;
+     * hierarchies of at most 4 nodes, 1 up to 64 nodes, 6 otherwise;
      * bits 16..31 queue entries a wave reserves per atomic (multiple of 64, 0 = auto).
      * Default 0x5518. */
     PTC_OPT_TUNE_TRAVERSAL = 9,
