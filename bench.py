@@ -91,6 +91,7 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=None, help="PTC_OPT_BATCH_PATHS")
     ap.add_argument("--builder", type=int, default=None, help="PTC_OPT_BVH_BUILDER")
     ap.add_argument("--tune", type=lambda v: int(v, 0), default=None, help="PTC_OPT_TUNE_TRAVERSAL value (experiments)")
+    ap.add_argument("--sort-rays", type=int, default=None, help="PTC_OPT_SORT_RAYS (experiments)")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="ranks only join a gloo group on the CPU and count themselves (tests the launcher without GPUs)")
     return ap.parse_args(argv)
@@ -201,6 +202,8 @@ def run_rank(args):
         opts[_ffi.OPT_BATCH_PATHS] = args.batch
     if args.builder is not None:
         opts[_ffi.OPT_BVH_BUILDER] = args.builder
+    if args.sort_rays is not None:
+        opts[_ffi.OPT_SORT_RAYS] = args.sort_rays
     r = Renderer(scene, device=local_rank, options=opts)
     sums = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda")
     r.bind_sum_buffer(sums.data_ptr(), sums.numel() * 4)

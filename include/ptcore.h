@@ -188,7 +188,12 @@ enum {
      * (one is bound by HBM, the other by the vector memory pipeline); the context's stream
      * waits for it before the results are used, so callers see ordinary stream order.
      * 0 = everything on the one stream. Results do not depend on it. */
-    PTC_OPT_OVERLAP_GATHER = 12
+    PTC_OPT_OVERLAP_GATHER = 12,
+    /* 1 = before the extension traversal of every bounce after the first, the live paths are reordered by
+     * (cell of the ray origin on a 128^3 grid, direction octant): a radix sort of 24-bit keys plus one pass
+     * that moves the packed state.  Results do not depend on it.  Default 0: on the dragon the more coherent
+     * traversal saves less than the sort costs. */
+    PTC_OPT_SORT_RAYS = 13
 };
 
 /* ----------------------------------------------------------- entry points -- */

@@ -904,6 +904,21 @@ std::string bvh_build(hipStream_t s, const BvhBuildInput& in, BvhBuildOutput& ou
     if (!err.empty()) return err;
     out.n_nodes = TOP_NODES + kt.n_tree_nodes + ks.n_tree_nodes;
     out.max_depth = std::max(kt.max_depth, ks.max_depth) + 2u;
+    {
+        Box6 sb = emptyBox();
+        for (const KindResult* k : {&kt, &ks}) {
+            if (k->has_tree) grow(sb, k->tree_box);
+            else if (k->n_small) grow(sb, k->small_box);
+        }
+        if (!(sb.lo[0] <= sb.hi[0])) {  // only large primitives: their box
+            if (kt.n_big) grow(sb, kt.big_box);
+            if (ks.n_big) grow(sb, ks.big_box);
+        }
+        for (int k = 0; k < 3; ++k) {
+            out.sort_lo[k] = std::isfinite(sb.lo[k]) ? sb.lo[k] : 0.f;
+            out.sort_hi[k] = std::isfinite(sb.hi[k]) ? sb.hi[k] : 1.f;
+        }
+    }
     if (out.max_depth > TRAV_LDS_STACK + TRAV_SPILL_STACK) return "BVH too deep for the traversal stack";
 
     // 4. top level

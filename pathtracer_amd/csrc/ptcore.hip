@@ -43,6 +43,10 @@ struct ptc_context {
     hipEvent_t ev_shadow = nullptr, ev_gather = nullptr;
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;  // build timing
     bool overlap_gather = true;
+    int sort_rays = 0;                          // PTC_OPT_SORT_RAYS
+    void* sort_temp = nullptr;                  // rocPRIM work space of the ray sort, for sort_temp_capacity paths
+    size_t sort_temp_bytes = 0;
+    uint32_t sort_temp_capacity = 0;
     std::string error;
 
     // scene (host copies of what was uploaded)
@@ -391,6 +395,29 @@ int runBounces(ptc_context* ctx, const RenderParams& rp, const DevScene& sc, uin
     while (count > 0 && bounce < max_iters) {
         uint32_t* grp = ctx->qcount + 8 * (bounce & 1u);  // {hit count, next count, shadow-ray count, extend work, shadow work, gather count}
         CHK(hipMemsetAsync(grp, 0, 6 * sizeof(uint32_t), ctx->stream));
+        if (ctx->sort_rays && bounce >= 1u && count >= 65536u && !ctx->no_alloc) {
+            // scattered rays, ordered by origin cell and direction octant.  The four queue / hit arrays are free at
+            // this point of a bounce (the last gather, which reads the gather queue, has to be through first).
+            if (gather_pending) {
+                CHK(hipStreamWaitEvent(ctx->stream, ctx->ev_gather, 0));
+                gather_pending = false;
+            }
+            if (ctx->sort_temp_capacity < ctx->ps.capacity) {
+                if (ctx->sort_temp) (void)hipFree(ctx->sort_temp);
+                ctx->sort_temp = nullptr;
+                ctx->sort_temp_capacity = 0;
+                ctx->sort_temp_bytes = ray_sort_temp_bytes(ctx->ps.capacity);
+                CHK(hipMalloc(&ctx->sort_temp, std::max<size_t>(ctx->sort_temp_bytes, 1)));
+                ctx->sort_temp_capacity = ctx->ps.capacity;
+            }
+            Timed t(ctx, 3);
+            CHK(ray_sort(ctx->stream, ctx->ps, count, ctx->bvh.sort_lo, ctx->bvh.sort_hi, ctx->hitq, (uint32_t*)ctx->ps.hit_t, ctx->gatherq, (uint32_t*)ctx->ps.hit_ref,
+                         ctx->sort_temp, ctx->sort_temp_bytes));
+            std::swap(ctx->ps.o_seed, ctx->ps.o_seed_next);
+            std::swap(ctx->ps.d_depth, ctx->ps.d_depth_next);
+            std::swap(ctx->ps.thr, ctx->ps.thr_next);
+            std::swap(ctx->ps.pid, ctx->ps.pid_next);
+        }
         {
             Timed t(ctx, 0);
             wf_extend(ctx->stream, rp, sc, ctx->ps, count, grp + 3, ctx->resident_waves, bounce == 0 && first_is_camera, ctx->count_trav != 0, ctx->counters);
@@ -607,6 +634,7 @@ int ptc_destroy(ptc_context* ctx) {
     for (void* p : {(void*)ctx->d_tris, (void*)ctx->d_spheres, (void*)ctx->d_materials, (void*)ctx->d_plights, (void*)ctx->d_dlights, (void*)ctx->d_qlights,
                     (void*)ctx->qcount, (void*)ctx->counters})
         if (p) (void)hipFree(p);
+    if (ctx->sort_temp) (void)hipFree(ctx->sort_temp);
     if (ctx->h_count) (void)hipHostFree(ctx->h_count);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -1042,6 +1070,7 @@ int ptc_set_option(ptc_context* ctx, int option, int64_t value) {
         case PTC_OPT_BRUTE_FORCE: ctx->brute_force = value != 0; break;
         case PTC_OPT_GROUP_HITS: ctx->group_hits = value != 0; break;
         case PTC_OPT_OVERLAP_GATHER: ctx->overlap_gather = value != 0; break;
+        case PTC_OPT_SORT_RAYS: ctx->sort_rays = value != 0; break;
         case PTC_OPT_BVH_BUILDER:
             if (value < 0 || value > 2) return fail(ctx, PTC_ERR_INVALID, "BVH builder must be 0 (LBVH), 1 (PLOC) or 2 (SAH sweep on the host)");
             ctx->bvh_builder = (int)value;

@@ -38,6 +38,16 @@ void wf_hit_records(hipStream_t s, const RenderParams& rp, const DevScene& sc, c
 void wf_probe_hits(hipStream_t s, const DevScene& sc, const PathState& ps, uint32_t count, int32_t* prim, float* t);
 void wf_eval_shading(hipStream_t s, int fn, uint32_t n, const float* in, float* out);
 
+// ---- ray sorting (ray_sort.hip) ------------------------------------------------
+// Reorders the live paths (entries [0, count) of o_seed / d_depth / thr / pid -> the same entries of the `*_next`
+// arrays, which the caller then swaps in) by a 24-bit key: Morton code of the ray origin's cell on a 128^3 grid
+// over [lo, hi] (21 bits) | direction octant (3 bits), so that the rays a wave traces start close together and
+// point the same way.  `k_in`, `k_out`, `v_in`, `v_out`: four scratch arrays of `count` words; `temp`: rocPRIM's
+// work space of ray_sort_temp_bytes(capacity) bytes.  Returns hipSuccess or the first error.
+size_t ray_sort_temp_bytes(uint32_t capacity);
+hipError_t ray_sort(hipStream_t s, const PathState& ps, uint32_t count, const float lo[3], const float hi[3], uint32_t* k_in, uint32_t* k_out, uint32_t* v_in,
+                    uint32_t* v_out, void* temp, size_t temp_bytes);
+
 // ---- BVH build (bvh_build.hip) ----------------------------------------------
 struct BvhBuildInput {
     const PtcTriangle* d_tris;   // device copies of the AoS uploads
@@ -63,6 +73,9 @@ struct BvhBuildOutput {  // device allocations owned by the caller afterwards
     WideNode* wnodes = nullptr;  // four-wide version of the hierarchy; null when it could not be built
     uint32_t n_wnodes = 0;
     uint32_t wide_depth = 0;
+    // box of the primitives that went into the trees (without the few "large" ones, e.g. a ground plane a
+    // thousand times the size of everything else): the grid the ray-sort keys are taken on
+    float sort_lo[3] = {0.f, 0.f, 0.f}, sort_hi[3] = {1.f, 1.f, 1.f};
 };
 
 // Returns an empty string on success, else an error message.

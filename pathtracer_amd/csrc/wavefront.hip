@@ -1273,7 +1273,9 @@ __device__ __forceinline__ vec3 gather_radiance(const RenderParams& rp, const De
 // Threads per block of k_surface.  With one or two light samples per hit: 256 (measured 256 > 512 by
 // 1-3 % > 1024 by 4 % more >> 128).  With many samples per hit every sample takes one queue atomic
 // per block, and the rate of atomics on one word (about 88 per microsecond) bounds the kernel: 1024.
+#ifndef SURF_BLOCK_FEW
 #define SURF_BLOCK_FEW 256
+#endif
 #define SURF_BLOCK_MANY 1024
 // One thread per path of the bounce that hit something.
 template <int INTEG>

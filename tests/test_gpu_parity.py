@@ -322,6 +322,25 @@ def test_gather_on_second_stream_does_not_change_results(rel, over):
     assert np.array_equal(out[0].view(np.uint32), out[1].view(np.uint32))
 
 
+@pytest.mark.parametrize("rel,over", [("scene4/dragon.test", dict(size="480 360", spp="4")), ("scene3/cornellRR.test", dict(size="192 192", spp="8")),
+                                      ("scene4/ggx.test", dict(size="640 140", spp="4"))])
+def test_ray_sorting_does_not_change_results(rel, over):
+    """PTC_OPT_SORT_RAYS reorders the live paths of every bounce after the first (origin cell, direction
+    octant); the packed state moves as a whole and radiance is addressed by path number: bit-identical sums
+    and the same ray counts."""
+    scene = load(rel, **over)
+    out = []
+    for sort in (0, 1):
+        r = Renderer(scene, options={_ffi.OPT_SEMANTICS: 1, _ffi.OPT_SEEDING: 1, _ffi.OPT_BOUNCE_CAP: 8, _ffi.OPT_SORT_RAYS: sort})
+        r.run()
+        st = r.stats()
+        out.append((r.sums(), st.extension_rays, st.shadow_rays))
+        r.close()
+    assert out[0][1] > 4 * 65536  # enough live paths for the sort to run
+    assert out[0][1:] == out[1][1:]
+    assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
+
+
 @pytest.mark.parametrize("kind,semantics", [("direct", 0), ("nee", 0), ("nee", 1), ("raytracer", 0)])
 def test_other_dragon_scenes(kind, semantics):
     """scene 2/dragon.test (direct, 50 stratified shadow rays per path), scene 3/dragon.test
