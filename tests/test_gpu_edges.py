@@ -191,6 +191,36 @@ def test_command_line_writes_the_same_png(tmp_path):
     assert bad.returncode == 0 and bad.stderr.strip()
 
 
+def test_command_line_multi_gpu_path(tmp_path):
+    """`pathtracer <scene> --gpus N`: one context, stream and host thread per device, samples split, ONE
+    ncclReduce of the sums to device 0, resolve there.  With the devices this box has (normally one, where the
+    communicator has a single rank) the image equals the single-GPU command line's with counter seeds byte for
+    byte; `--ordered-sum` (host adds in device order) as well; asking for more GPUs than present is an error."""
+    import torch
+    exe = os.path.join(ROOT, "pathtracer_amd", "_lib", "pathtracer")
+    base = override_scene_text(scene_text("scene3/cornellRR.test"), size="96 80", spp="6", maxdepth="6")
+    imgs = {}
+    for tag, flags in (("single", []), ("rccl", ["--gpus", "1"]), ("ordered", ["--gpus", "1", "--ordered-sum"])):
+        path = tmp_path / f"{tag}.test"
+        path.write_text(override_scene_text(base, output=str(tmp_path / f"{tag}.png")))
+        out = subprocess.run([exe, str(path), "--intended", "--counter-seeds"] + flags, capture_output=True, text=True, timeout=180)
+        assert out.returncode == 0 and f"{tag}.png is saved." in out.stdout, out.stdout + out.stderr
+        if flags:
+            assert "rendering on 1 GPU(s)" in out.stdout
+        imgs[tag] = read_png(str(tmp_path / f"{tag}.png"))
+    assert np.array_equal(imgs["single"], imgs["rccl"]) and np.array_equal(imgs["single"], imgs["ordered"])
+    assert imgs["single"][..., :3].max() > 0
+    n = torch.cuda.device_count()
+    if n >= 2:  # a multi-GPU box: the split over all devices against the single-GPU image (summation order differs)
+        path = tmp_path / "all.test"
+        path.write_text(override_scene_text(base, output=str(tmp_path / "all.png")))
+        out = subprocess.run([exe, str(path), "--intended", "--counter-seeds", "--gpus", str(n)], capture_output=True, text=True, timeout=300)
+        assert f"rendering on {n} GPU(s)" in out.stdout, out.stdout + out.stderr
+        assert np.abs(read_png(str(tmp_path / "all.png")).astype(int) - imgs["single"].astype(int)).max() <= 1
+    bad = subprocess.run([exe, str(tmp_path / "single.test"), "--gpus", str(n + 1)], capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 0 and f"asked for {n + 1} GPUs, {n} present" in bad.stderr
+
+
 def soup(n_tris, n_spheres, seed, degenerate=False):
     """Random triangle soup (+ ellipsoids) around the origin with the camera inside it."""
     rng = np.random.default_rng(seed)
