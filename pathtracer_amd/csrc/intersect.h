@@ -231,7 +231,14 @@ template <int LDS_N = TRAV_LDS_STACK>
 __device__ __forceinline__ uint32_t trav_pop(const uint32_t* lds_stack, const uint32_t* spill, int& sp) {
     if (sp == 0) return REF_DONE;
     --sp;
-    return sp < LDS_N ? lds_stack[sp * TRAV_BLOCK] : spill[sp - LDS_N];
+    // The LDS entry is read unconditionally (index clamped) and replaced in the rare deep case: written as one
+    // conditional expression the compiler selects between the two ADDRESSES and emits a flat load, which goes
+    // through the vector memory pipeline -- the unit these kernels keep busiest -- instead of a ds_read.
+    // (a volatile access is the one thing it neither merges nor sinks)
+    typedef __attribute__((address_space(3))) const volatile uint32_t lds_word;
+    uint32_t v = *(lds_word*)&lds_stack[(sp < LDS_N ? sp : LDS_N - 1) * TRAV_BLOCK];
+    if (sp >= LDS_N) v = spill[sp - LDS_N];
+    return v;
 }
 
 // A ray whose direction has a NaN component can never be accepted by either
@@ -533,7 +540,11 @@ __device__ __forceinline__ bool traverse_simple(const DevScene& sc, vec3 o, vec3
         }
         if (sp == 0) break;
         --sp;
-        cur = sp < TRAV_LDS_STACK ? lds_stack[sp * TRAV_BLOCK] : spill[sp - TRAV_LDS_STACK];
+        {  // see trav_pop
+            typedef __attribute__((address_space(3))) const volatile uint32_t lds_word;
+            cur = *(lds_word*)&lds_stack[(sp < TRAV_LDS_STACK ? sp : TRAV_LDS_STACK - 1) * TRAV_BLOCK];
+            if (sp >= TRAV_LDS_STACK) cur = spill[sp - TRAV_LDS_STACK];
+        }
     }
     return false;
 }
