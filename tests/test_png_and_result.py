@@ -38,3 +38,27 @@ def test_png_round_trip(tmp_path):
     except ImportError:
         return
     assert np.array_equal(np.array(Image.open(path)), img)
+
+
+def test_png_compresses_and_decodes_identically(tmp_path):
+    """Adaptive filters + LZ77 + dynamic Huffman codes: smooth and flat images shrink a lot, noise does not
+    grow by more than the container overhead, and every image decodes to the bytes that went in (checked with
+    zlib through the test's own PNG reader)."""
+    import os
+    rng = np.random.default_rng(5)
+    y, x = np.mgrid[0:96, 0:160]
+    smooth = np.stack([(x * 255 // 159), (y * 255 // 95), ((x + y) * 255 // 254), np.full_like(x, 255)], axis=-1).astype(np.uint8)
+    flat = np.zeros((300, 500, 4), dtype=np.uint8)
+    flat[..., 3] = 255
+    flat[100:200, 100:300, :3] = (10, 200, 30)
+    noise = rng.integers(0, 256, size=(64, 64, 4), dtype=np.uint8)
+    render_like = np.clip(smooth.astype(int) + rng.integers(-6, 7, size=smooth.shape), 0, 255).astype(np.uint8)
+    render_like[..., 3] = 255
+    skewed = (rng.exponential(0.7, size=(80, 120, 4)).astype(int) % 256).astype(np.uint8)  # a few very frequent values: long and short codes
+    tiny = np.array([[[1, 2, 3, 255]]], dtype=np.uint8)
+    for name, img, max_ratio in (("smooth", smooth, 0.15), ("flat", flat, 0.01), ("noise", noise, 1.02), ("render_like", render_like, 0.75),
+                                 ("skewed", skewed, 0.5), ("tiny", tiny, 50.0)):
+        path = str(tmp_path / (name + ".png"))
+        resultToPNG(path, img.shape[1], img.shape[0], img.tobytes())
+        assert np.array_equal(read_png(path), img), name
+        assert os.path.getsize(path) <= max_ratio * img.nbytes + 100, (name, os.path.getsize(path), img.nbytes)
