@@ -109,27 +109,38 @@ def launch_ranks(n, argv):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].stdout.read().decode()
-    rcs = []
+    # Watch all ranks: one that fails ends the job at once (the others may be blocked in the rendezvous waiting for it).
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
     deadline = time.time() + 1800
-    for p in procs:
-        try:
-            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
-        except subprocess.TimeoutExpired:
-            p.kill()
-            rcs.append(-9)
-    if any(rcs):
+    failed = None
+    while failed is None and time.time() < deadline:
+        states = [p.poll() for p in procs]
+        if any(rc not in (None, 0) for rc in states):
+            failed = states
+        elif all(rc == 0 for rc in states):
+            break
+        else:
+            time.sleep(0.1)
+    if failed is not None or any(p.poll() is None for p in procs):
         for p in procs:
             if p.poll() is None:
                 p.kill()
-        sys.stderr.write(f"bench.py: ranks exited with {rcs}\n")
+        for p in procs:
+            p.wait()
+        sys.stderr.write(f"bench.py: ranks exited with {[p.returncode for p in procs]}\n")
         return 1
-    sys.stdout.write(out0)
+    reader.join(timeout=10)
+    sys.stdout.write(b"".join(chunks).decode())
     sys.stdout.flush()
     return 0
 
 
 def launcher_selftest(rank, world):
+    if os.environ.get("BENCH_SELFTEST_FAIL_RANK") == str(rank):  # a rank that dies before the rendezvous
+        return 3
     import torch
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)

@@ -117,6 +117,12 @@ def test_bench_launcher_starts_the_ranks_it_reports(tmp_path):
         p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], env=env,
                            capture_output=True, timeout=300)
         assert p.returncode != 0 and not p.stdout.decode().strip()
+    # a rank that dies before the rendezvous: the launcher ends the job at once instead of waiting with the others
+    import time
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launcher-selftest"], env=dict(env, BENCH_SELFTEST_FAIL_RANK="1"),
+                       capture_output=True, timeout=120)
+    assert p.returncode != 0 and not p.stdout.decode().strip() and time.time() - t0 < 60
     # --gpus must agree with the launcher's WORLD_SIZE
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--launcher-selftest"], env=dict(env, WORLD_SIZE="2", RANK="0"),
                        capture_output=True, timeout=120)
