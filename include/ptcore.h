@@ -168,7 +168,7 @@ enum {
      * 4 = refilling waves with deferred primitive tests (leaf primitives go to a
      * per-wave queue in LDS and are tested 64 at a time) over the two-child nodes,
      * 6 = the same over the four-wide nodes with 8-bit child boxes, 5 = automatic: 0 for
-     * hierarchies of at most 4 nodes, 1 up to 64 nodes, 6 otherwise;
+     * hierarchies of at most 6 (shadow rays: 8) nodes, 1 up to 64 nodes, 6 otherwise;
      * bits 16..31 queue entries a wave reserves per atomic (multiple of 64, 0 = auto).
      * Default 0x5518. */
     PTC_OPT_TUNE_TRAVERSAL = 9,
@@ -176,7 +176,9 @@ enum {
      * Morton codes), 1 = PLOC (locally-ordered clustering, better trees; default),
      * 2 = top-down surface-area-heuristic sweep on the host (single-threaded, ten times
      * the build time; 6 % fewer node visits for extension rays, 11 % more for shadow
-     * rays than PLOC on the dragon: +1.4 % throughput). */
+     * rays than PLOC on the dragon: +1.4 % throughput).  Scenes of at most 1024
+     * primitives of a kind always get 2, and no "large primitive" leaf: in a Cornell box
+     * every wall is as large as the scene. */
     PTC_OPT_BVH_BUILDER = 10,
     /* 1 (default) = when a scene mixes shading classes (triangle / sphere hits, Phong / GGX
      * materials) the hits of a bounce are grouped by class before the surface kernel runs,

@@ -603,7 +603,18 @@ void sahBuild(const std::vector<Box6>& boxes, const std::vector<uint32_t>& prims
 std::string buildKind(hipStream_t s, const Box6* d_boxes, const std::vector<Box6>& boxes, uint32_t kind, float pad, int builder, BvhNode* d_nodes,
                       uint32_t node_base, KindResult& res) {
     std::vector<uint32_t> small, big;
-    classify(boxes, small, big);
+#ifndef SMALL_SCENE_PRIMS
+#define SMALL_SCENE_PRIMS 1024u
+#endif
+    if (boxes.size() <= SMALL_SCENE_PRIMS && boxes.size() > BVH_LEAF_MAX) {
+        // A few primitives (a Cornell box: every wall is as large as the scene): no "large primitive" leaf that
+        // every ray would have to test, and the surface-area sweep on the host, which costs nothing at this size
+        // and copes with mixed sizes.
+        for (uint32_t i = 0; i < boxes.size(); ++i) small.push_back(i);
+        builder = 2;
+    } else {
+        classify(boxes, small, big);
+    }
     res.n_small = (uint32_t)small.size();
     res.n_big = (uint32_t)big.size();
     res.small_box = emptyBox();

@@ -1602,14 +1602,18 @@ static uint32_t deferred_resident_waves() {
     return cache[dev];
 }
 
-// Automatic kernel choice by hierarchy size (measured on the Cornell boxes): with a handful of nodes every ray does
-// the same few steps and the one-ray-per-lane loop wins (12 triangles + 1 sphere, 4 nodes: static 7090, refilling
-// rounds 6940 Mrays/s); a few more nodes and the rays' step counts differ enough for refilling waves to pay (24
-// triangles + 1 sphere: static 5250, refilling rounds 5820, deferred tests 5430 Mrays/s); real meshes take the
-// deferred tests over the four-wide nodes.
-#define STATIC_BVH_NODES 4u
+// Automatic kernel choice by hierarchy size (measured on the small scenes, whose trees come from the SAH sweep):
+// with a handful of nodes every ray does the same few steps and the one-ray-per-lane loop wins (scene 2
+// sphere.test, 6 nodes: static 830, refilling rounds 730 Mrays/s); a few more and the rays' step counts differ
+// enough for refilling waves to pay, for the closest-hit rays first (Cornell box + GGX sphere, 8 nodes: extension
+// 184 ms refilling / 192 ms static, shadow 62 / 53 ms; cornellRR, 13 nodes: 53 / 60 and 21 / 24 ms); real meshes
+// take the deferred tests over the four-wide nodes.
+#define STATIC_EXT_NODES 6u
+#define STATIC_SHADOW_NODES 8u
 #define TINY_BVH_NODES 64u
-static uint32_t auto_mode(const DevScene& sc) { return sc.n_nodes <= STATIC_BVH_NODES ? 0u : sc.n_nodes <= TINY_BVH_NODES ? 1u : 6u; }
+static uint32_t auto_mode(const DevScene& sc, bool shadow) {
+    return sc.n_nodes <= (shadow ? STATIC_SHADOW_NODES : STATIC_EXT_NODES) ? 0u : sc.n_nodes <= TINY_BVH_NODES ? 1u : 6u;
+}
 
 // The item word of the deferred-test kernels holds 25 bits of primitive slot.
 static bool deferred_fits(const DevScene& sc) { return sc.n_tris < (1u << 25) && sc.n_spheres < (1u << 25); }
@@ -1620,7 +1624,7 @@ void wf_extend(hipStream_t s, const RenderParams& rp, const DevScene& sc, const 
     uint32_t blocks, wave_chunk;
     // mode 5 (default): see auto_mode; the deferred tests serve the camera rays as well (5 % faster than the
     // static kernel on the dragon)
-    uint32_t mode = rp.tune_mode == 3 ? (coherent ? 0u : 1u) : rp.tune_mode == 5 ? auto_mode(sc) : rp.tune_mode;
+    uint32_t mode = rp.tune_mode == 3 ? (coherent ? 0u : 1u) : rp.tune_mode == 5 ? auto_mode(sc, false) : rp.tune_mode;
     const bool wide = mode == 6 && sc.wnodes != nullptr;  // mode 6: deferred tests over the four-wide nodes
     if (mode == 6) mode = 4;
     if (mode == 4 && !deferred_fits(sc)) mode = 1;
@@ -1652,7 +1656,7 @@ void wf_shadow(hipStream_t s, const RenderParams& rp, const DevScene& sc, const 
                uint32_t* work_counter, uint32_t resident_waves, bool count_trav, unsigned long long* trav_counters, unsigned long long* shadow_total) {
     if (max_rays == 0) return;
     uint32_t blocks, wave_chunk;
-    uint32_t smode = rp.tune_shadow == 5 ? auto_mode(sc) : rp.tune_shadow;
+    uint32_t smode = rp.tune_shadow == 5 ? auto_mode(sc, true) : rp.tune_shadow;
     const bool wide = smode == 6 && sc.wnodes != nullptr;
     if (smode == 6) smode = 4u;
     if (smode == 4 && !deferred_fits(sc)) smode = 1u;
