@@ -364,11 +364,13 @@ __device__ __forceinline__ uint32_t wide_eval(const WideData& nd, const TravRay&
     const uint32_t nz = pz ? nd.w2.x : nd.w2.w, fz = pz ? nd.w2.w : nd.w2.x;
     const uint4 w3 = *nd.refs;
     uint32_t key[4], ref[4] = {w3.x, w3.y, w3.z, w3.w};
+    bool hit[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const float tn = fmaxf(max3f(__builtin_fmaf(byte_f(nx, c), sx, bx), __builtin_fmaf(byte_f(ny, c), sy, by), __builtin_fmaf(byte_f(nz, c), sz, bz)), r.tmin);
         const float tf = fminf(min3f(__builtin_fmaf(byte_f(fx, c), sx, bx), __builtin_fmaf(byte_f(fy, c), sy, by), __builtin_fmaf(byte_f(fz, c), sz, bz)), lim);
-        key[c] = (tn <= tf && ref[c] != REF_EMPTY_WORD) ? __float_as_uint(tn) : 0xFFFFFFFFu;
+        hit[c] = (tn <= tf) & (ref[c] != REF_EMPTY_WORD);  // no short circuit: both sides are cheap, a branch is not
+        key[c] = hit[c] ? __float_as_uint(tn) : 0xFFFFFFFFu;
     }
     if (SORT) {
         wide_order(key[0], ref[0], key[1], ref[1]);
@@ -392,14 +394,22 @@ __device__ __forceinline__ uint32_t wide_eval(const WideData& nd, const TravRay&
         if (key[0] != 0xFFFFFFFFu) return ref[0];
         return trav_pop<LDS_N>(lds_stack, spill, sp);
     }
-    uint32_t next = REF_DONE;
-#pragma unroll
-    for (int c = 3; c >= 0; --c) {
-        if (key[c] == 0xFFFFFFFFu) continue;
-        if (next != REF_DONE) trav_push<LDS_N>(lds_stack, spill, sp, next);
-        next = ref[c];
+    // storage order: the first hit child is visited next, the later ones are pushed last to first
+    const bool p3 = hit[3] & (hit[0] | hit[1] | hit[2]), p2 = hit[2] & (hit[0] | hit[1]), p1 = hit[1] & hit[0];
+    if (sp + 3 <= LDS_N) {  // the same branch-free pushes as above
+        lds_stack[sp * TRAV_BLOCK] = ref[3];
+        sp += p3 ? 1 : 0;
+        lds_stack[sp * TRAV_BLOCK] = ref[2];
+        sp += p2 ? 1 : 0;
+        lds_stack[sp * TRAV_BLOCK] = ref[1];
+        sp += p1 ? 1 : 0;
+    } else {
+        if (p3) trav_push<LDS_N>(lds_stack, spill, sp, ref[3]);
+        if (p2) trav_push<LDS_N>(lds_stack, spill, sp, ref[2]);
+        if (p1) trav_push<LDS_N>(lds_stack, spill, sp, ref[1]);
     }
-    return next != REF_DONE ? next : trav_pop<LDS_N>(lds_stack, spill, sp);
+    if (hit[0] | hit[1] | hit[2] | hit[3]) return hit[0] ? ref[0] : hit[1] ? ref[1] : hit[2] ? ref[2] : ref[3];
+    return trav_pop<LDS_N>(lds_stack, spill, sp);
 }
 
 // Visit one internal node.

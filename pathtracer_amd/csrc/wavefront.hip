@@ -635,7 +635,13 @@ __global__ __launch_bounds__(BLOCK, DQ_MIN_WAVES) void k_trace_deferred(RenderPa
             }
             if (leaf) {
                 const uint32_t first = REF_FIRST(cur);
-                for (uint32_t k = 0; k < n; ++k) items[qn + pre + k] = DQ_ITEM(lane, kind == REF_SPHERE, first + k);
+                // predicated stores at fixed offsets (a loop over k becomes a loop with exec-mask bookkeeping per round)
+                uint32_t* dst = items + qn + pre;
+                const uint32_t item0 = DQ_ITEM(lane, kind == REF_SPHERE, first);
+                dst[0] = item0;  // a leaf holds at least one primitive
+#pragma unroll
+                for (uint32_t k = 1; k < DQ_LEAF; ++k)
+                    if (k < n) dst[k] = item0 + k;
                 // a longer leaf keeps its remainder for the next step
                 cur = have > n ? MAKE_LEAF(kind, first + n, have - n) : trav_pop<DQ_STACK>(my_stack, spill, sp);
             }
