@@ -466,14 +466,17 @@ __device__ __forceinline__ void deferred_item(const DevScene& sc, DeferredLds& L
     const float tmax = PT_RAY_MAX;
     const float t_best = u2f((uint32_t)(L.best[rt] >> 32));
     Cand c;
+    // the primitive's global index is fetched together with the primitive, not after the test: an accepted
+    // candidate would otherwise cost the whole wave a second memory round trip per batch
+    uint32_t prim = (uint32_t)(sphere ? sc.sph_prim[slot] : sc.tri_prim[slot]);
     if (sphere) {
         c = sphere_candidate(sc.spheres[slot], o, d, nullptr);
     } else {
         const float4* q = sc.tri_q + 3 * (size_t)slot;
         c = tri_candidate(q[0], q[1], q[2], o, d, tmin, t_best);
     }
+    asm volatile("" : "+v"(prim));  // keeps the load above the branch
     if (!c.hit || !(c.t > tmin && c.t < tmax) || c.t > t_best) return;
-    const uint32_t prim = (uint32_t)(sphere ? sc.sph_prim[slot] : sc.tri_prim[slot]);
     const unsigned long long key = ((unsigned long long)f2u(c.t) << 32) | prim;
     atomicMin(&L.best[rt], key);
     if (L.best[rt] == key) L.best_ref[rt] = sphere ? HIT_SPHERE(slot) : (int)slot;
