@@ -297,7 +297,9 @@ __device__ __forceinline__ uint32_t wave_fetch(WaveWork& w, bool idle, uint32_t*
     if (w.pos >= w.end && !w.drained) {
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(counter, wave_chunk);
-        base = __shfl(base, 0);
+        // a scalar broadcast (all lanes of the wave are here): the compiler then knows that the span, and with it
+        // every branch that depends on it, is wave-uniform
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
         w.pos = base;
         w.end = min(base + wave_chunk, count);
         if (base >= count) {
@@ -430,7 +432,9 @@ __global__ __launch_bounds__(BLOCK) void k_shadow_static(RenderParams rp, DevSce
 #define DQ_STACK 12                         /* LDS stack entries per ray; deeper ones in scratch */
 #endif
 #define DQ_SPILL (TRAV_LDS_STACK + TRAV_SPILL_STACK - DQ_STACK)
-#define DQ_LEAF 4u                          /* primitives a lane queues per step */
+#ifndef DQ_LEAF
+#define DQ_LEAF 3u                          /* primitives a lane queues per step (3 = BVH_LEAF_MAX: two ballots give the queue positions; 4 needs three: -2 %) */
+#endif
 #define DQ_ITEMS (64 + 64 * DQ_LEAF)        /* < 64 left over + DQ_LEAF per lane */
 #define DQ_ITEM(lane, sphere, slot) (((lane) << 26) | ((sphere) ? 0x2000000u : 0u) | (slot))
 
@@ -628,10 +632,10 @@ __global__ __launch_bounds__(BLOCK, DQ_MIN_WAVES) void k_trace_deferred(RenderPa
         if (COUNT) st_leaf += (uint32_t)__popcll(__ballot(leaf));
         if (__any(leaf)) {
             const uint32_t have = leaf ? REF_COUNT(cur) : 0u;
-            const uint32_t n = have < DQ_LEAF ? have : DQ_LEAF;  // 0..4
+            const uint32_t n = have < DQ_LEAF ? have : DQ_LEAF;  // 0..DQ_LEAF
             uint32_t pre = 0u, tot = 0u;
 #pragma unroll
-            for (uint32_t b = 0; b < 3u; ++b) {
+            for (uint32_t b = 0; b < (DQ_LEAF > 3u ? 3u : 2u); ++b) {
                 const unsigned long long m = __ballot(((n >> b) & 1u) != 0u);
                 pre += (uint32_t)__popcll(m & lt_mask) << b;
                 tot += (uint32_t)__popcll(m) << b;
