@@ -1290,9 +1290,12 @@ __device__ __forceinline__ vec3 gather_radiance(const RenderParams& rp, const De
 #define SURF_BLOCK_FEW 256
 #endif
 #define SURF_BLOCK_MANY 1024
+#ifndef SURF_WAVES
+#define SURF_WAVES 5   /* waves per SIMD the register allocation aims at */
+#endif
 // One thread per path of the bounce that hit something.
 template <int INTEG>
-__global__ __launch_bounds__(SURF_BLOCK_MANY, 5) void k_surface(RenderParams rp, DevScene sc, PathState ps, const uint32_t* __restrict__ queue,
+__global__ __launch_bounds__(SURF_BLOCK_MANY, SURF_WAVES) void k_surface(RenderParams rp, DevScene sc, PathState ps, const uint32_t* __restrict__ queue,
                                                        const uint32_t* __restrict__ count_ptr, uint32_t npix_pad, uint32_t sample_begin, uint32_t* __restrict__ segctr,
                                                        uint32_t* __restrict__ next_count,
                                                        uint32_t* __restrict__ gather_queue, uint32_t* __restrict__ gather_count,
