@@ -355,12 +355,13 @@ __device__ __forceinline__ void wide_order(uint32_t& ka, uint32_t& ra, uint32_t&
 // next and pushes the other hit children.  SORT: nearest first (closest-hit rays); without
 // it the children go in storage order (any-hit rays, where every hit child has to be
 // visited anyway unless an occluder turns up).
-// `o` is the ray origin (the caller may keep it outside of its registers; r.o and r.nox..noz are not used).
 template <bool SORT, int LDS_N = TRAV_LDS_STACK>
-__device__ __forceinline__ uint32_t wide_eval(const WideData& nd, const TravRay& r, vec3 o, float lim, uint32_t* lds_stack, uint32_t* spill, int& sp) {
-    // plane distance of grid coordinate q along x: (origin.x + q*scale.x - o.x)/d.x = q*sx + bx
+__device__ __forceinline__ uint32_t wide_eval(const WideData& nd, const TravRay& r, float lim, uint32_t* lds_stack, uint32_t* spill, int& sp) {
+    // plane distance of grid coordinate q along x: (origin.x + q*scale.x - o.x)/d.x = q*sx + bx, bx = origin.x/d.x - o.x/d.x
     const float sx = __uint_as_float(nd.w0.w) * r.ix, sy = __uint_as_float(nd.w1.x) * r.iy, sz = __uint_as_float(nd.w1.y) * r.iz;
-    const float bx = (__uint_as_float(nd.w0.x) - o.x) * r.ix, by = (__uint_as_float(nd.w0.y) - o.y) * r.iy, bz = (__uint_as_float(nd.w0.z) - o.z) * r.iz;
+    // -o/d is kept in registers: one FMA per axis (the boxes are padded for the rounding of o/d, as for the two-box nodes)
+    const float bx = __builtin_fmaf(__uint_as_float(nd.w0.x), r.ix, r.nox), by = __builtin_fmaf(__uint_as_float(nd.w0.y), r.iy, r.noy),
+                bz = __builtin_fmaf(__uint_as_float(nd.w0.z), r.iz, r.noz);
     // the planes the ray enters / leaves through, per axis, for all four children at once
     const bool px = r.ix >= 0.f, py = r.iy >= 0.f, pz = r.iz >= 0.f;
     const uint32_t nx = px ? nd.w1.z : nd.w2.y, fx = px ? nd.w2.y : nd.w1.z;

@@ -619,9 +619,7 @@ __global__ __launch_bounds__(BLOCK, DQ_MIN_WAVES) void k_trace_deferred(RenderPa
             if (COUNT) cnt.nodes++;
             const float lim = ANY ? r.tmax : u2f((uint32_t)(L.best[tid] >> 32));
             if (WIDE) {
-                // the origin comes from LDS, where the queued tests read it: six registers fewer than keeping -o/d
-                const float2 r0 = L.ray[0][tid];
-                cur = wide_eval<!ANY, DQ_STACK>(wd, r, mk3(r0.x, r0.y, L.ray[1][tid].x), lim, my_stack, spill, sp);
+                cur = wide_eval<!ANY, DQ_STACK>(wd, r, lim, my_stack, spill, sp);
             } else {
                 cur = node_eval<DQ_STACK>(nd, r, lim, my_stack, spill, sp);
             }
