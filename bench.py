@@ -281,7 +281,7 @@ def run_rank(args):
         on_chip_gbs = (b_ext * st.extension_rays / extend_s / 1e9) if extend_s > 0 else 0.0
         q = quoted_counters(args.workload, args.semantics, overridden)
         roofline = {
-            "kernel": "extension-ray traversal (k_trace_deferred<false> over four-wide nodes; k_extend_static for hierarchies of at most 64 nodes)",
+            "kernel": "extension-ray traversal (k_trace_deferred<false> over four-wide nodes; k_extend_static / k_extend for hierarchies of at most 6 / 64 nodes)",
             "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": int(st.extend_launches), "rays_per_launch": round(rays_per_launch, 1),
             "nodes_per_ray": round(nodes_per_ray, 2), "prims_per_ray": round(prims_per_ray, 2),
             "algorithmic_bytes_per_ray": round(b_ext, 1), "algorithmic_bytes_per_launch": round(b_ext * rays_per_launch, 1),
