@@ -824,6 +824,10 @@ bool collapseWide(const std::vector<BvhNode>& bin, std::vector<WideNode>& wide, 
             ch.erase(ch.begin() + pick);
             ch.insert(ch.end(), tmp.begin(), tmp.end());
         }
+        // Storage order = the order in which any-hit rays visit the children that they hit: smallest box first (an
+        // occluder is found sooner in a small box than in a large one; measured against largest first, leaves first
+        // and internal nodes first).  Closest-hit rays sort by entry distance and do not care.
+        std::stable_sort(ch.begin(), ch.end(), [](const WideChild& a, const WideChild& b) { return boxArea(a.box) < boxArea(b.box); });
         WideNode out;
         std::memset(&out, 0, sizeof(out));
         for (int c = 0; c < 4; ++c) out.child[c] = REF_EMPTY_WORD;
