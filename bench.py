@@ -326,7 +326,7 @@ def run_rank(args):
             "shadow_mrays_per_s": round(shadow_rays / dt / 1e6, 2),
             "bounces_per_path": round(ext_rays / max(paths, 1), 3),
             "batch": {"paths": int(st.batch_paths), "path_state_GB": round(st.path_state_bytes / 1e9, 2)},
-            "bvh": {"nodes": int(st.bvh_nodes), "max_depth": int(st.bvh_max_depth), "build_ms": round(st.build_ms, 2)},
+            "bvh": {"builder": 3 if args.builder is None else args.builder, "nodes": int(st.bvh_nodes), "max_depth": int(st.bvh_max_depth), "build_ms": round(st.build_ms, 2)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

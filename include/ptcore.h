@@ -173,10 +173,13 @@ enum {
      * Default 0x5518. */
     PTC_OPT_TUNE_TRAVERSAL = 9,
     /* Hierarchy builder used by the next ptc_build: 0 = LBVH (Karras radix tree over
-     * Morton codes), 1 = PLOC (locally-ordered clustering, better trees; default),
+     * Morton codes), 1 = PLOC (locally-ordered clustering, better trees),
      * 2 = top-down surface-area-heuristic sweep on the host (single-threaded, ten times
      * the build time; 6 % fewer node visits for extension rays, 11 % more for shadow
-     * rays than PLOC on the dragon: +1.4 % throughput).  Scenes of at most 1024
+     * rays than PLOC on the dragon: +1.4 % throughput), 3 (default) = two hierarchies, the
+     * sweep's for the closest-hit rays and PLOC's for the any-hit rays (both build times,
+     * both memory footprints, +2.4 % on the dragon; same images; scenes of more than 2^20
+     * primitives get 1, the sweep is a host job).  Scenes of at most 1024
      * primitives of a kind always get 2, and no "large primitive" leaf: in a Cornell box
      * every wall is as large as the scene. */
     PTC_OPT_BVH_BUILDER = 10,

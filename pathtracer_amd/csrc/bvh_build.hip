@@ -20,6 +20,10 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include <rocprim/rocprim.hpp>
@@ -539,28 +543,28 @@ void sahBuild(const std::vector<Box6>& boxes, const std::vector<uint32_t>& prims
         }
         box[i] = b;
     }
-    std::vector<int> idx(n), tmp(n);
+    std::vector<int> idx(n);
     for (int i = 0; i < n; ++i) idx[i] = i;
-    std::vector<float> suffix(n + 1);
     struct Job {
         int first, count, node;  // idx[first, first+count) -> internal node `node` (n-based)
     };
-    int next_internal = n;
+    std::atomic<int> next_internal(n);
     root = next_internal++;
-    std::vector<Job> jobs{{0, n, root}};
     auto area = [](const Box6& b) {
         const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
         return dx * dy + dy * dz + dz * dx;
     };
-    while (!jobs.empty()) {
-        const Job j = jobs.back();
-        jobs.pop_back();
+    // One split: a job only touches its own range of idx and its own node, so jobs run on any thread; the node
+    // labels depend on the schedule, the tree does not.
+    auto split = [&](const Job& j, std::vector<int>& tmp, std::vector<float>& suffix, Job out[2]) -> int {
         int* a = idx.data() + j.first;
         Box6 nb = emptyBox();
         for (int i = 0; i < j.count; ++i) grow(nb, box[a[i]]);
         box[j.node] = nb;
         int best_axis = -1, best_split = j.count / 2;
         float best_cost = INFINITY;
+        if ((int)tmp.size() < j.count) tmp.resize(j.count);
+        if ((int)suffix.size() < j.count + 1) suffix.resize(j.count + 1);
         for (int k = 0; k < 3 && j.count > 2; ++k) {
             std::copy(a, a + j.count, tmp.begin());
             std::sort(tmp.begin(), tmp.begin() + j.count, [&](int x, int y) { return cen[k][x] < cen[k][y] || (cen[k][x] == cen[k][y] && x < y); });
@@ -584,19 +588,69 @@ void sahBuild(const std::vector<Box6>& boxes, const std::vector<uint32_t>& prims
         if (best_axis >= 0)
             std::sort(a, a + j.count, [&](int x, int y) { return cen[best_axis][x] < cen[best_axis][y] || (cen[best_axis][x] == cen[best_axis][y] && x < y); });
         const int nl = best_split, nr = j.count - best_split;
-        int child[2];
+        int child[2], n_out = 0;
         const int firsts[2] = {j.first, j.first + nl}, counts[2] = {nl, nr};
         for (int c = 0; c < 2; ++c) {
             if (counts[c] == 1) {
                 child[c] = idx[firsts[c]];
             } else {
                 child[c] = next_internal++;
-                jobs.push_back({firsts[c], counts[c], child[c]});
+                out[n_out++] = Job{firsts[c], counts[c], child[c]};
             }
         }
         left[j.node - n] = child[0];
         right[j.node - n] = child[1];
-    }
+        return n_out;
+    };
+    // Large jobs go through a shared list (so that the two halves of a split run on different threads), small ones
+    // are finished by the thread that made them.
+    const int SHARE_MIN = 4096;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<Job> shared{{0, n, root}};
+    int pending = 1;  // jobs in `shared` or being split by a thread (under `mu`)
+    auto worker = [&]() {
+        std::vector<int> tmp;
+        std::vector<float> suffix;
+        std::vector<Job> local;
+        for (;;) {
+            Job j;
+            {
+                std::unique_lock<std::mutex> lock(mu);
+                cv.wait(lock, [&] { return !shared.empty() || pending == 0; });
+                if (shared.empty()) return;
+                j = shared.back();
+                shared.pop_back();
+            }
+            local.assign(1, j);
+            while (!local.empty()) {
+                const Job cur = local.back();
+                local.pop_back();
+                Job out[2];
+                const int n_out = split(cur, tmp, suffix, out);
+                for (int c = 0; c < n_out; ++c) {
+                    if (out[c].count >= SHARE_MIN) {
+                        std::lock_guard<std::mutex> lock(mu);
+                        shared.push_back(out[c]);
+                        ++pending;
+                        cv.notify_one();
+                    } else {
+                        local.push_back(out[c]);
+                    }
+                }
+            }
+            {
+                std::lock_guard<std::mutex> lock(mu);
+                if (--pending == 0) cv.notify_all();
+            }
+        }
+    };
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int n_threads = n < 2 * SHARE_MIN ? 1 : (int)std::min<unsigned>(8u, std::max<unsigned>(1u, hw));
+    std::vector<std::thread> pool;
+    for (int t = 1; t < n_threads; ++t) pool.emplace_back(worker);
+    worker();
+    for (std::thread& t : pool) t.join();
 }
 
 // Tree over the small primitives of one kind (builder 0: LBVH, 1: PLOC, 2: host SAH sweep); writes the emitted nodes to nodes[node_base..].

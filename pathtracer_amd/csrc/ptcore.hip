@@ -73,6 +73,8 @@ struct ptc_context {
     PtcDirectionalLight* d_dlights = nullptr;
     PtcQuadLight* d_qlights = nullptr;
     BvhBuildOutput bvh;
+    BvhBuildOutput bvh_any;   // builder 3 only: the hierarchy (and primitive order) the any-hit rays traverse
+    bool two_trees = false;
     bool built = false;
 
     // render targets
@@ -105,7 +107,7 @@ struct ptc_context {
     int semantics = 0, seeding = 0, cull_zero = 1, profile = 0, count_trav = 0, brute_force = 0;
     uint32_t bounce_cap = 1024;
     uint64_t batch_paths = 512u << 20;
-    int bvh_builder = 1;
+    int bvh_builder = 3;
     uint32_t tune_refill = 24, tune_mode = 5, tune_shadow = 5, tune_chunk = 0;
 
     PtcStats stats{};
@@ -329,6 +331,24 @@ DevScene deviceScene(const ptc_context* c) {
     return sc;
 }
 
+// The scene as the any-hit (shadow) rays see it: with PTC_OPT_BVH_BUILDER 3 a hierarchy of their own, with the
+// primitives in that hierarchy's leaf order (nothing but occlusion is read from it).
+DevScene deviceSceneAny(const ptc_context* c) {
+    DevScene sc = deviceScene(c);
+    if (!c->two_trees) return sc;
+    sc.tri_q = c->bvh_any.tri_q;
+    sc.tri_mat = c->bvh_any.tri_mat;
+    sc.tri_prim = c->bvh_any.tri_prim;
+    sc.spheres = c->bvh_any.spheres;
+    sc.sph_mat = c->bvh_any.sph_mat;
+    sc.sph_prim = c->bvh_any.sph_prim;
+    sc.nodes = c->bvh_any.nodes;
+    sc.wnodes = c->bvh_any.wnodes;
+    sc.n_wnodes = c->bvh_any.n_wnodes;
+    sc.n_nodes = c->bvh_any.n_nodes;
+    return sc;
+}
+
 int makeParams(ptc_context* ctx, int frame_id, uint32_t w, uint32_t h, RenderParams& rp) {
     if (!ctx->have_cfg) return fail(ctx, PTC_ERR_INVALID, "ptc_set_config has not been called");
     if (ctx->integrator < 0) return fail(ctx, PTC_ERR_INVALID, "ptc_set_integrator has not been called");
@@ -376,6 +396,7 @@ int uploadLights(ptc_context* ctx) {
     return PTC_OK;
 }
 
+#define TWO_TREES_MAX_PRIMS (1u << 20)  /* builder 3 above this size: one PLOC hierarchy */
 #define N_COUNTERS 24  /* [0..3] nodes / primitives (extension, shadow), [4] shadow rays, [5..6] maxima, [8..14] / [16..22] schedule statistics of the deferred kernel */
 #define N_QCOUNT 20
 
@@ -389,6 +410,7 @@ int runBounces(ptc_context* ctx, const RenderParams& rp, const DevScene& sc, uin
     uint32_t count = count0;
     uint32_t bounce = 0;
     const uint32_t S = rp.samples_per_path;
+    const DevScene sc_any = deviceSceneAny(ctx);
     // k_gather only adds to L; hit compaction does too when there is a background colour
     const bool overlap = ctx->overlap_gather && !(rp.bg[0] != 0.f || rp.bg[1] != 0.f || rp.bg[2] != 0.f);
     bool gather_pending = false;
@@ -440,7 +462,7 @@ int runBounces(ptc_context* ctx, const RenderParams& rp, const DevScene& sc, uin
         if (S) {
             {
                 Timed t(ctx, 1);
-                wf_shadow(ctx->stream, rp, sc, ctx->ps, grp + 2, (uint64_t)count * S, grp + 4, ctx->resident_waves, ctx->count_trav != 0, ctx->counters, ctx->counters + 4);
+                wf_shadow(ctx->stream, rp, sc_any, ctx->ps, grp + 2, (uint64_t)count * S, grp + 4, ctx->resident_waves, ctx->count_trav != 0, ctx->counters, ctx->counters + 4);
             }
             if (overlap) {
                 CHK(hipEventRecord(ctx->ev_shadow, ctx->stream));
@@ -631,6 +653,7 @@ int ptc_destroy(ptc_context* ctx) {
     freeTargets(ctx);
     freePaths(ctx);
     bvh_free(ctx->bvh);
+    bvh_free(ctx->bvh_any);
     for (void* p : {(void*)ctx->d_tris, (void*)ctx->d_spheres, (void*)ctx->d_materials, (void*)ctx->d_plights, (void*)ctx->d_dlights, (void*)ctx->d_qlights,
                     (void*)ctx->qcount, (void*)ctx->counters})
         if (p) (void)hipFree(p);
@@ -756,6 +779,8 @@ int ptc_build(ptc_context* ctx) {
     CHK(upload(ctx->d_tris, ctx->tris, ctx->stream));
     CHK(upload(ctx->d_spheres, ctx->spheres, ctx->stream));
     bvh_free(ctx->bvh);
+    bvh_free(ctx->bvh_any);
+    ctx->two_trees = false;
     BvhBuildInput in{};
     in.d_tris = ctx->d_tris;
     in.n_tris = (uint32_t)ctx->tris.size();
@@ -763,11 +788,20 @@ int ptc_build(ptc_context* ctx) {
     in.n_spheres = (uint32_t)ctx->spheres.size();
     in.h_tri_mat = tmat.data();
     in.h_sph_mat = smat.data();
-    in.builder = ctx->bvh_builder;
+    // two hierarchies while the host sweep stays well under a second; PLOC alone beyond that
+    const bool two = ctx->bvh_builder == 3 && ctx->tris.size() + ctx->spheres.size() <= TWO_TREES_MAX_PRIMS;
+    in.builder = ctx->bvh_builder == 3 ? (two ? 2 : 1) : ctx->bvh_builder;
     in.extra_extent = ctx->have_cfg ? std::max(fabsf(ctx->cfg.eye.x), std::max(fabsf(ctx->cfg.eye.y), fabsf(ctx->cfg.eye.z))) : 0.f;
     std::string err = bvh_build(ctx->stream, in, ctx->bvh);
+    if (err.empty() && two) {  // closest-hit rays: SAH sweep (above); any-hit rays: PLOC
+        in.builder = 1;
+        err = bvh_build(ctx->stream, in, ctx->bvh_any);
+        ctx->two_trees = err.empty();
+    }
     if (!err.empty()) {
         bvh_free(ctx->bvh);
+        bvh_free(ctx->bvh_any);
+        ctx->two_trees = false;
         return fail(ctx, PTC_ERR_DEVICE, err);
     }
     CHK(hipEventRecord(e1, ctx->stream));
@@ -1072,7 +1106,7 @@ int ptc_set_option(ptc_context* ctx, int option, int64_t value) {
         case PTC_OPT_OVERLAP_GATHER: ctx->overlap_gather = value != 0; break;
         case PTC_OPT_SORT_RAYS: ctx->sort_rays = value != 0; break;
         case PTC_OPT_BVH_BUILDER:
-            if (value < 0 || value > 2) return fail(ctx, PTC_ERR_INVALID, "BVH builder must be 0 (LBVH), 1 (PLOC) or 2 (SAH sweep on the host)");
+            if (value < 0 || value > 3) return fail(ctx, PTC_ERR_INVALID, "BVH builder must be 0 (LBVH), 1 (PLOC), 2 (SAH sweep on the host) or 3 (2 for closest-hit rays, 1 for any-hit rays)");
             ctx->bvh_builder = (int)value;
             ctx->built = false;
             break;

@@ -202,16 +202,18 @@ def test_pathtracer_glass_and_volume(rel, material, head, semantics, seeding):
 
 
 def test_bvh_builders_agree():
-    """LBVH, PLOC and host-SAH trees give the same hits and the same image, bit for bit."""
+    """LBVH, PLOC and host-SAH trees, and the pair of trees of builder 3 (SAH for the closest-hit rays, PLOC for the
+    any-hit rays), give the same hits and the same image, bit for bit."""
     scene = load("scene4/dragon.test", size="160 120", spp="2")
     out = []
-    for builder in (0, 1, 2):
+    for builder in (0, 1, 2, 3):
         r = Renderer(scene, options={_ffi.OPT_BVH_BUILDER: builder, _ffi.OPT_SEMANTICS: 1, _ffi.OPT_SEEDING: 1})
         hits = r.primary_hits()
         r.run()
         out.append((hits, r.sums(), r.stats().bvh_nodes))
         r.close()
-    assert len({o[2] for o in out}) == 3  # really three different trees
+    assert len({o[2] for o in out}) == 3  # really three different trees (builder 3 reports its closest-hit tree: builder 2's)
+    assert out[3][2] == out[2][2]
     for other in out[1:]:
         for f in ("prim", "t", "u", "v"):
             assert np.array_equal(out[0][0][f].view(np.uint32), other[0][f].view(np.uint32))
