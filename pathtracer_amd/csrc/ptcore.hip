@@ -405,8 +405,9 @@ int uploadLights(ptc_context* ctx) {
 // survivors -> next queue), shadow, gather (radiance of the segments that sampled the lights).  Queue
 // lengths stay on the device; the grids are sized by the bounce's path count; the next
 // queue's length is the one word read back.
-int runBounces(ptc_context* ctx, const RenderParams& rp, const DevScene& sc, uint32_t count0, uint32_t sample_begin, uint32_t max_iters = 0xFFFFFFFFu,
+int runBounces(ptc_context* ctx, const RenderParams& rp_frame, const DevScene& sc, uint32_t count0, uint32_t sample_begin, uint32_t max_iters = 0xFFFFFFFFu,
                uint32_t* survivors = nullptr, bool first_is_camera = true) {
+    RenderParams rp = rp_frame;
     uint32_t count = count0;
     uint32_t bounce = 0;
     const uint32_t S = rp.samples_per_path;
@@ -415,6 +416,8 @@ int runBounces(ptc_context* ctx, const RenderParams& rp, const DevScene& sc, uin
     const bool overlap = ctx->overlap_gather && !(rp.bg[0] != 0.f || rp.bg[1] != 0.f || rp.bg[2] != 0.f);
     bool gather_pending = false;
     while (count > 0 && bounce < max_iters) {
+        // camera segments of a batch whose sums k_generate did not seed: this bounce writes them
+        rp.init_L = (bounce == 0 && first_is_camera && rp.seeding != 0) ? 1u : 0u;
         uint32_t* grp = ctx->qcount + 8 * (bounce & 1u);  // {hit count, next count, shadow-ray count, extend work, shadow work, gather count}
         CHK(hipMemsetAsync(grp, 0, 6 * sizeof(uint32_t), ctx->stream));
         if (ctx->sort_rays && bounce >= 1u && count >= 65536u && !ctx->no_alloc) {

@@ -271,12 +271,13 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_generate(RenderParams rp, PathSta
         ps.o_seed[at] = make_float4(cf.eye.x, cf.eye.y, cf.eye.z, u2f(seed));
         ps.d_depth[at] = make_float4(dir.x, dir.y, dir.z, u2f(0u));
         ps.pid[at] = p;
-        float4 L = make_float4(0.f, 0.f, 0.f, 0.f);
+        // the path's radiance sum: seeded with the pixel's running sum (reference order of additions), or left to
+        // the first bounce, which writes it (RenderParams::init_L) -- every camera segment ends in exactly one of a
+        // miss, a hit that adds its radiance directly, or a hit that goes through the gather kernel
         if (seed_L_from_acc) {
             const float* a = acc + 3 * ((size_t)y * rp.width + x);
-            L = make_float4(a[0], a[1], a[2], 0.f);
+            ps.L[p] = make_float4(a[0], a[1], a[2], 0.f);
         }
-        ps.L[p] = L;
     }
 }
 
@@ -711,9 +712,9 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_compact_hits(RenderParams rp, Dev
                     cls = (ref >= 0 ? 0u : 2u) | (sc.materials[mat & ~MAT_LIGHT_BIT].brdf_type == PTC_GGX ? 1u : 0u);
                 }
                 stream[c] = cls * GEN_CHUNKS + c;
-            } else if (bg) {
+            } else if (bg || rp.init_L) {
                 const uint32_t p = ps.pid[i];
-                float4 L = ps.L[p];
+                float4 L = rp.init_L ? make_float4(0.f, 0.f, 0.f, 0.f) : ps.L[p];
                 L.x += rp.bg[0];
                 L.y += rp.bg[1];
                 L.z += rp.bg[2];
@@ -1406,7 +1407,7 @@ __global__ __launch_bounds__(SURF_BLOCK_MANY, SURF_WAVES) void k_surface(RenderP
             // formulas over zero terms, here
             vec3 radiance = out.a;
             if (out.gather) radiance = gather_radiance<INTEG>(rp, sc, ps, i, out.a, thr_before, !rp.cf.next_event_est || depth_before == 0u);
-            float4 L = ps.L[p];
+            float4 L = rp.init_L ? make_float4(0.f, 0.f, 0.f, 0.f) : ps.L[p];
             L.x += radiance.x;  // PinholeCamera.cu:61
             L.y += radiance.y;
             L.z += radiance.z;
@@ -1467,7 +1468,7 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(RenderParams rp, DevSce
     const uint32_t p = f2u(t4.w);
     const vec3 a = mk3(a4.x, a4.y, a4.z), thr = mk3(t4.x, t4.y, t4.z);
     const vec3 radiance = gather_radiance<INTEG>(rp, sc, ps, seg, a, thr, f2u(a4.w) != 0u);
-    float4 L = ps.L[p];
+    float4 L = rp.init_L ? make_float4(0.f, 0.f, 0.f, 0.f) : ps.L[p];
     L.x += radiance.x;  // PinholeCamera.cu:61
     L.y += radiance.y;
     L.z += radiance.z;
