@@ -23,6 +23,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <mutex>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -648,7 +649,11 @@ void sahBuild(const std::vector<Box6>& boxes, const std::vector<uint32_t>& prims
     const unsigned hw = std::thread::hardware_concurrency();
     const int n_threads = n < 2 * SHARE_MIN ? 1 : (int)std::min<unsigned>(8u, std::max<unsigned>(1u, hw));
     std::vector<std::thread> pool;
-    for (int t = 1; t < n_threads; ++t) pool.emplace_back(worker);
+    try {
+        for (int t = 1; t < n_threads; ++t) pool.emplace_back(worker);
+    } catch (const std::system_error&) {
+        // no more threads to be had: the ones that did start and this one do the work
+    }
     worker();
     for (std::thread& t : pool) t.join();
 }
