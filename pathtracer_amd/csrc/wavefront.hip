@@ -251,6 +251,9 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_generate(RenderParams rp, PathSta
         j += sample_begin;
         valid = pixel_of(rp, pix, x, y);
     }
+    // The 64 paths of a wave are one sample of one 8x8 tile (path_number): telling the compiler so turns the
+    // jump-ahead of the jitter stream below, a loop of 32-bit multiplies, into scalar code.
+    j = (uint32_t)__builtin_amdgcn_readfirstlane((int)j);
     // live paths are kept packed: this one's state goes to position `at`
     const uint32_t at = queue_reserve(valid, qcount);
     if (valid) {
