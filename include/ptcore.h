@@ -178,7 +178,7 @@ enum {
      * the build time; 6 % fewer node visits for extension rays, 11 % more for shadow
      * rays than PLOC on the dragon: +1.4 % throughput), 3 (default) = two hierarchies, the
      * sweep's for the closest-hit rays and PLOC's for the any-hit rays (both build times,
-     * both memory footprints, +2.4 % on the dragon; same images; scenes of more than 2^20
+     * both memory footprints, +2.4 % on the dragon; same images; scenes of more than 2^19
      * primitives get 1, the sweep is a host job).  Scenes of at most 1024
      * primitives of a kind always get 2, and no "large primitive" leaf: in a Cornell box
      * every wall is as large as the scene. */

@@ -264,7 +264,11 @@ __global__ void k_ploc_nn(const int* __restrict__ cluster, int m, const Box6* __
     for (int j = lo; j <= hi; ++j) {
         if (j == i) continue;
         const float a = union_area(me, node_box[cluster[j]]);
-        if (a < best) {  // ties keep the lowest position
+        // Ties go to the nearest position, and between the two nearest to the partner i^1: a run of coincident
+        // primitives then pairs up completely in every round (a balanced subtree) instead of merging one pair per
+        // round (a chain as deep as the run is long).
+        const int dj = abs(j - i), db = abs(bj - i);
+        if (a < best || (a == best && bj >= 0 && (dj < db || (dj == db && j == (i ^ 1))))) {
             best = a;
             bj = j;
         }
@@ -579,7 +583,9 @@ void sahBuild(const std::vector<Box6>& boxes, const std::vector<uint32_t>& prims
             for (int i = 1; i < j.count; ++i) {
                 grow(acc, box[tmp[i - 1]]);
                 const float cost = area(acc) * (float)i + suffix[i] * (float)(j.count - i);
-                if (cost < best_cost) {
+                // equal costs (coincident primitives: every split costs the same): the most even split, or the
+                // subtree becomes a chain
+                if (cost < best_cost || (cost == best_cost && std::abs(2 * i - j.count) < std::abs(2 * best_split - j.count))) {
                     best_cost = cost;
                     best_axis = k;
                     best_split = i;

@@ -396,7 +396,7 @@ int uploadLights(ptc_context* ctx) {
     return PTC_OK;
 }
 
-#define TWO_TREES_MAX_PRIMS (1u << 20)  /* builder 3 above this size: one PLOC hierarchy */
+#define TWO_TREES_MAX_PRIMS (1u << 19)  /* builder 3 above this size: one PLOC hierarchy */
 #define N_COUNTERS 24  /* [0..3] nodes / primitives (extension, shadow), [4] shadow rays, [5..6] maxima, [8..14] / [16..22] schedule statistics of the deferred kernel */
 #define N_QCOUNT 20
 
@@ -795,10 +795,21 @@ int ptc_build(ptc_context* ctx) {
     const bool two = ctx->bvh_builder == 3 && ctx->tris.size() + ctx->spheres.size() <= TWO_TREES_MAX_PRIMS;
     in.builder = ctx->bvh_builder == 3 ? (two ? 2 : 1) : ctx->bvh_builder;
     in.extra_extent = ctx->have_cfg ? std::max(fabsf(ctx->cfg.eye.x), std::max(fabsf(ctx->cfg.eye.y), fabsf(ctx->cfg.eye.z))) : 0.f;
-    std::string err = bvh_build(ctx->stream, in, ctx->bvh);
+    // A hierarchy the traversal stack cannot hold (clustering and sweep follow the geometry, and some geometry
+    // makes chains) is built again as a radix tree over the Morton codes, whose depth is bounded by the key length.
+    auto build = [&](int builder, BvhBuildOutput& out) {
+        in.builder = builder;
+        std::string e = bvh_build(ctx->stream, in, out);
+        if (!e.empty() && builder != 0 && e.find("too deep") != std::string::npos) {
+            bvh_free(out);
+            in.builder = 0;
+            e = bvh_build(ctx->stream, in, out);
+        }
+        return e;
+    };
+    std::string err = build(in.builder, ctx->bvh);
     if (err.empty() && two) {  // closest-hit rays: SAH sweep (above); any-hit rays: PLOC
-        in.builder = 1;
-        err = bvh_build(ctx->stream, in, ctx->bvh_any);
+        err = build(1, ctx->bvh_any);
         ctx->two_trees = err.empty();
     }
     if (!err.empty()) {

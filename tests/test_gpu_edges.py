@@ -246,7 +246,7 @@ def soup(n_tris, n_spheres, seed, degenerate=False):
     return SceneLoader().loadText("\n".join(lines) + "\n")
 
 
-@pytest.mark.parametrize("builder", [0, 1])
+@pytest.mark.parametrize("builder", [0, 1, 2, 3])
 @pytest.mark.parametrize("case", [dict(n_tris=6000, n_spheres=60, seed=11), dict(n_tris=3000, n_spheres=0, seed=12, degenerate=True)])
 def test_random_soups_against_brute_force(case, builder):
     """Camera inside a cloud of small, huge, coincident and zero-area primitives: every
@@ -267,6 +267,33 @@ def test_random_soups_against_brute_force(case, builder):
         for f in ("prim", "t", "u", "v"):
             assert np.array_equal(hits[f].view(np.uint32), want_hits[f].view(np.uint32)), (hex(tune), f)
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), hex(tune)
+
+
+@pytest.mark.parametrize("builder", [0, 1, 2, 3])
+def test_many_coincident_primitives(builder):
+    """600 exact copies of one triangle inside a soup (an instanced mesh exported twice, stacked decals ...): the
+    clustering and the sweep must pair the copies up evenly -- merged one pair per round, or split off one at a
+    time, they make a chain deeper than the traversal stack and the build is refused."""
+    import ctypes as C
+    scene = soup(n_tris=1500, n_spheres=0, seed=5)
+    n = len(scene.triangles)
+    raw = np.frombuffer(scene.triangles, dtype=np.uint8).reshape(n, C.sizeof(_ffi.Triangle)).copy()
+    out = np.concatenate([raw, np.tile(raw[:1], (600, 1))])
+    scene.triangles = (_ffi.Triangle * len(out)).from_buffer_copy(out.tobytes())
+    b = Renderer(scene, options={_ffi.OPT_BRUTE_FORCE: 1})
+    want_hits = b.primary_hits()
+    b.run()
+    want = b.sums()
+    b.close()
+    r = Renderer(scene, options={_ffi.OPT_BVH_BUILDER: builder})
+    assert r.stats().bvh_max_depth <= 40
+    hits = r.primary_hits()
+    r.run()
+    got = r.sums()
+    r.close()
+    for f in ("prim", "t", "u", "v"):
+        assert np.array_equal(hits[f].view(np.uint32), want_hits[f].view(np.uint32)), f
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
 @pytest.mark.parametrize("far", ["1e30", "3e38"])
