@@ -92,6 +92,9 @@ def parse_args(argv=None):
     ap.add_argument("--builder", type=int, default=None, help="PTC_OPT_BVH_BUILDER")
     ap.add_argument("--tune", type=lambda v: int(v, 0), default=None, help="PTC_OPT_TUNE_TRAVERSAL value (experiments)")
     ap.add_argument("--sort-rays", type=int, default=None, help="PTC_OPT_SORT_RAYS (experiments)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal on a box with fewer GPUs than ranks: every rank renders on GPU 0 and the collectives run through gloo "
+                         "on host copies (RCCL refuses a device that appears twice); the line then reports n_gpus 1 and the rank count")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="ranks only join a gloo group on the CPU and count themselves (tests the launcher without GPUs)")
     return ap.parse_args(argv)
@@ -133,7 +136,9 @@ def launch_ranks(n, argv):
         sys.stderr.write(f"bench.py: ranks exited with {[p.returncode for p in procs]}\n")
         return 1
     reader.join(timeout=10)
-    sys.stdout.write(b"".join(chunks).decode())
+    # rank 0's result line goes to stdout; whatever else a library printed there (gloo announces its connections) to stderr
+    for line in b"".join(chunks).decode(errors="replace").splitlines():
+        (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line + "\n")
     sys.stdout.flush()
     return 0
 
@@ -183,15 +188,22 @@ def run_rank(args):
         return launcher_selftest(rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    shared = args.share_gpu and world > 1
+    if shared:
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"rank {rank} wants GPU {local_rank} but only {torch.cuda.device_count()} are visible")
     torch.cuda.set_device(local_rank)
+    cdev = "cpu" if shared else "cuda"  # where the small collectives' tensors live
     joined = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        j = torch.ones(1, dtype=torch.int64, device="cuda")
-        dist.all_reduce(j)  # the ranks that really joined the RCCL group
+        if shared:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        j = torch.ones(1, dtype=torch.int64, device=cdev)
+        dist.all_reduce(j)  # the ranks that really joined the group
         joined = int(j[0])
         if joined != world:
             raise SystemExit(f"{joined} of {world} ranks joined")
@@ -222,7 +234,7 @@ def run_rank(args):
 
     def step():
         # this rank's share of the global sample index space, then one RCCL reduce
-        split_render_step(r, sums, rank, world, spp, dist, ordered=args.ordered_reduce)
+        split_render_step(r, sums, rank, world, spp, dist, ordered=args.ordered_reduce, stage_on_host=shared)
 
     def sync():
         torch.cuda.synchronize()
@@ -256,8 +268,8 @@ def run_rank(args):
     st = r.stats()
     r.set_option(_ffi.OPT_PROFILE, 0)
 
-    tvals = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    counts = torch.tensor([st.extension_rays, st.shadow_rays, st.paths], dtype=torch.float64, device="cuda")
+    tvals = torch.tensor([dt], dtype=torch.float64, device=cdev)
+    counts = torch.tensor([st.extension_rays, st.shadow_rays, st.paths], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(tvals, op=dist.ReduceOp.MAX)
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
@@ -316,12 +328,12 @@ def run_rank(args):
             cpu = cpu_baseline(args, scene)
         out = {
             "metric": "Mrays/s (paths x bounces)", "value": round(ext_rays / dt / 1e6, 2), "unit": "Mrays/s",
-            "n_gpus": joined, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+            "n_gpus": 1 if shared else joined, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "the reference's own scene file (scenes/" + WORKLOADS[args.workload]["scene"] + ") at the config's size and sample count; nothing synthetic, no weights",
             "config": {"workload": WORKLOADS[args.workload]["name"] + (" [overridden]" if overridden else ""),
                        "width": W, "height": H, "spp_per_gpu": spp, "spp_total": spp * world, "semantics": "intended" if args.semantics else "literal",
-                       "seeding": "counter", "parallelism": f"spp-split x{world}", "reduce": "rank-ordered gather + add" if args.ordered_reduce else "one sum-reduce to rank 0"},
+                       "seeding": "counter", "parallelism": f"spp-split x{world}" + (" (rehearsal: all ranks on one GPU, gloo)" if shared else ""), "reduce": "rank-ordered gather + add" if args.ordered_reduce else "one sum-reduce to rank 0"},
             "total_mrays_per_s": round((ext_rays + shadow_rays) / dt / 1e6, 2),
             "shadow_mrays_per_s": round(shadow_rays / dt / 1e6, 2),
             "bounces_per_path": round(ext_rays / max(paths, 1), 3),

@@ -29,10 +29,12 @@ void coreCheck(ptc_context* c, int rc) {
 }
 }  // namespace
 
-MultiGpuRenderer::MultiGpuRenderer(std::shared_ptr<Scene> scene_, int n_devices, bool ordered_sum) : scene(scene_), ordered(ordered_sum) {
+MultiGpuRenderer::MultiGpuRenderer(std::shared_ptr<Scene> scene_, int n_devices, bool ordered_sum, bool share_devices)
+    : scene(scene_), ordered(ordered_sum) {
     int present = 0;
     hipCheck(hipGetDeviceCount(&present), "hipGetDeviceCount");
-    if (n_devices < 1 || n_devices > present)
+    if (share_devices && !ordered_sum) throw std::runtime_error("devices can only be shared with the ordered sum (an RCCL communicator cannot hold a device twice)");
+    if (n_devices < 1 || present < 1 || (n_devices > present && !share_devices))
         throw std::runtime_error("asked for " + std::to_string(n_devices) + " GPUs, " + std::to_string(present) + " present");
     width = scene->width;
     height = scene->height;
@@ -41,9 +43,9 @@ MultiGpuRenderer::MultiGpuRenderer(std::shared_ptr<Scene> scene_, int n_devices,
         for (int g = 0; g < n_devices; ++g) {
             Dev* d = new Dev;
             devs.push_back(d);
-            d->device = g;
-            if (ptc_create(g, &d->ctx) != PTC_OK) throw std::runtime_error(ptc_last_error(nullptr));
-            hipCheck(hipSetDevice(g), "hipSetDevice");
+            d->device = g % present;
+            if (ptc_create(d->device, &d->ctx) != PTC_OK) throw std::runtime_error(ptc_last_error(nullptr));
+            hipCheck(hipSetDevice(d->device), "hipSetDevice");
             hipCheck(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking), "hipStreamCreate");
             hipCheck(hipMalloc((void**)&d->sums, bytes), "hipMalloc");
             ptc_context* c = d->ctx;
@@ -65,7 +67,7 @@ MultiGpuRenderer::MultiGpuRenderer(std::shared_ptr<Scene> scene_, int n_devices,
         if (!ordered) {
             std::vector<ncclComm_t> comms(n_devices);
             std::vector<int> ids(n_devices);
-            for (int g = 0; g < n_devices; ++g) ids[g] = g;
+            for (int g = 0; g < n_devices; ++g) ids[g] = devs[g]->device;
             ncclCheck(ncclCommInitAll(comms.data(), n_devices, ids.data()), "ncclCommInitAll");
             for (int g = 0; g < n_devices; ++g) devs[g]->comm = comms[g];
         }

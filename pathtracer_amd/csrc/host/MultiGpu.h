@@ -24,8 +24,11 @@ class MultiGpuRenderer {
     void release();  // contexts, communicators, buffers, streams
 
 public:
-    // devices 0 .. n_devices-1; throws std::runtime_error (fewer devices present, HIP / RCCL errors, core errors)
-    MultiGpuRenderer(std::shared_ptr<Scene> scene, int n_devices, bool ordered_sum = false);
+    // devices 0 .. n_devices-1; throws std::runtime_error (fewer devices present, HIP / RCCL errors, core errors).
+    // `share_devices` (with `ordered_sum` only: a communicator cannot hold one device twice) lets n_devices exceed the
+    // devices present: context g then lives on device g mod present.  It is how a one-GPU machine runs the
+    // several-context path (threads, sample ranges, ordered sum); it is not faster than one context.
+    MultiGpuRenderer(std::shared_ptr<Scene> scene, int n_devices, bool ordered_sum = false, bool share_devices = false);
     ~MultiGpuRenderer();
     MultiGpuRenderer(const MultiGpuRenderer&) = delete;
     MultiGpuRenderer& operator=(const MultiGpuRenderer&) = delete;

@@ -5,7 +5,8 @@
 // "Elapsed time: <s> seconds", write the PNG and print "<file> is saved.".
 // Exceptions are printed and the exit status stays 0 like the reference
 // (main.cpp:47-52).  Extra, optional flags select the build-only options; `--gpus N` renders the frame on N GPUs of
-// the node (samples split, one RCCL reduce; `--ordered-sum`: deterministic host adds instead).
+// the node (samples split, one RCCL reduce; `--ordered-sum`: deterministic host adds instead; with it `--share-devices`
+// allows more contexts than devices, which is how a one-GPU machine exercises the several-context path).
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -26,6 +27,7 @@ struct Options {
     std::vector<std::pair<int, long long>> core;
     int gpus = 0;  // 0: the reference's single-GPU Renderer; N >= 1: MultiGpuRenderer over N devices (RCCL reduce)
     bool ordered = false;
+    bool share = false;  // more contexts than devices (ordered sum only): the several-context path on a one-GPU machine
 };
 
 Options parse(int argc, char** argv) {
@@ -37,6 +39,7 @@ Options parse(int argc, char** argv) {
         else if (!std::strcmp(argv[i], "--bounce-cap") && i + 1 < argc) o.core.push_back({PTC_OPT_BOUNCE_CAP, std::atoll(argv[++i])});
         else if (!std::strcmp(argv[i], "--gpus") && i + 1 < argc) o.gpus = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--ordered-sum")) o.ordered = true;
+        else if (!std::strcmp(argv[i], "--share-devices")) o.share = true;
         else throw std::runtime_error(std::string("unknown option ") + argv[i]);
     }
     return o;
@@ -78,7 +81,7 @@ int main(int argc, char** argv) {
         std::shared_ptr<Scene> scene = loader.load(argv[1]);
         const Options o = parse(argc, argv);
         if (o.gpus >= 1) {
-            MultiGpuRenderer multi(scene, o.gpus, o.ordered);
+            MultiGpuRenderer multi(scene, o.gpus, o.ordered, o.share);
             std::cout << "rendering on " << multi.deviceCount() << " GPU(s), sums combined by " << (o.ordered ? "ordered host adds" : "one RCCL reduce") << std::endl;
             MultiRun run{multi};
             renderAndSave(run, o);

@@ -37,15 +37,23 @@ def ordered_reduce(sums, rank: int, world: int, dist):
         sums.copy_(acc)
 
 
-def split_render_step(renderer, sums, rank: int, world: int, spp_per_rank: int, dist=None, ordered: bool = False):
+def split_render_step(renderer, sums, rank: int, world: int, spp_per_rank: int, dist=None, ordered: bool = False,
+                      stage_on_host: bool = False):
     """One whole-job render.  `renderer` accumulates into `sums` (a tensor it was
-    bound to); `dist` is torch.distributed (needed when world > 1)."""
+    bound to, rendering on the stream torch uses -- Renderer.set_stream -- so that the
+    collective is ordered after the render); `dist` is torch.distributed (needed when
+    world > 1).  `stage_on_host`: the combine runs on host copies of the sums, for
+    process groups that cannot move device memory (gloo) -- which is how several ranks
+    that share ONE GPU rehearse the whole path (RCCL refuses a device that appears twice)."""
     j0, j1 = sample_range(rank, world, spp_per_rank)
     renderer.render_range(j0, j1, clear=True)
     if world > 1:
+        buf = sums.cpu() if stage_on_host else sums  # .cpu() waits for the render on torch's stream
         if ordered:
-            ordered_reduce(sums, rank, world, dist)
+            ordered_reduce(buf, rank, world, dist)
         else:
-            dist.reduce(sums, dst=0, op=dist.ReduceOp.SUM)
+            dist.reduce(buf, dst=0, op=dist.ReduceOp.SUM)
+        if stage_on_host and rank == 0:
+            sums.copy_(buf)
     if rank == 0:
         renderer.resolve(world * spp_per_rank)

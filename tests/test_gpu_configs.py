@@ -151,3 +151,42 @@ def test_dragon_refract(semantics):
     bm_g, bm_w = block_mean(np.where(fin, gsum, 0), 8), block_mean(np.where(fin, wsum, 0), 8)
     assert np.sqrt(((bm_g - bm_w) ** 2).mean()) / max(np.abs(bm_w).mean(), 1e-6) <= 0.05
     assert abs(int(st.extension_rays) - int(ost.extension_rays)) <= 0.01 * ost.extension_rays + 16
+
+
+@pytest.mark.parametrize("world,ordered", [(2, False), (3, True)])
+def test_ranks_sharing_one_gpu(tmp_path, world, ordered):
+    """The one-process-per-GPU path with the real renderer: `world` processes (all on this box's GPU, which RCCL
+    would refuse, so the combine goes through gloo on host copies), each renders its share of the samples,
+    rank 0 combines and resolves.  The sums must equal, bit for bit, the ranges rendered one after the other by one
+    process and added in rank order (two ranks: the only order there is; three: the ordered reduce)."""
+    import socket
+    import subprocess
+    import sys
+    import torch
+    spp = 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpu_rank_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(rank), str(world), port, str(tmp_path), "1" if ordered else "0", str(spp)],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for rank in range(world)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    got_sums, got = np.load(tmp_path / "sums.npy"), np.load(tmp_path / "result.npy")
+    scene = SceneLoader().loadText(override_scene_text(scene_text("scene3/cornellRR.test"), size="96 80", spp=str(spp * world), maxdepth="6"))
+    r = Renderer(scene, options={_ffi.OPT_SEMANTICS: 1, _ffi.OPT_SEEDING: 1})
+    buf = torch.zeros(80 * 96 * 3, dtype=torch.float32, device="cuda")
+    r.bind_sum_buffer(buf.data_ptr(), buf.numel() * 4)
+    total = None
+    for g in range(world):
+        r.render_range(g * spp, (g + 1) * spp, clear=True)
+        r.synchronize()
+        total = buf.clone() if total is None else total + buf
+    buf.copy_(total)
+    torch.cuda.synchronize()
+    r.resolve(spp * world)
+    want = r.result()
+    r.close()
+    assert np.array_equal(got_sums.view(np.uint32), total.cpu().numpy().view(np.uint32))
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert got.max() > 0

@@ -221,6 +221,41 @@ def test_command_line_multi_gpu_path(tmp_path):
     assert bad.returncode == 0 and f"asked for {n + 1} GPUs, {n} present" in bad.stderr
 
 
+def test_command_line_several_contexts_on_one_device(tmp_path):
+    """`--gpus 3 --ordered-sum --share-devices` on whatever devices are present: three contexts, three host threads,
+    the sample ranges [0,2) [2,4) [4,6), host adds in context order.  The image must be the one obtained by
+    rendering those ranges one after the other on one context and adding the three sums in that order."""
+    import torch
+    from pathtracer_amd import _ffi as ffi
+    exe = os.path.join(ROOT, "pathtracer_amd", "_lib", "pathtracer")
+    text = override_scene_text(scene_text("scene3/cornellRR.test"), size="96 80", spp="6", maxdepth="6", output=str(tmp_path / "three.png"))
+    path = tmp_path / "three.test"
+    path.write_text(text)
+    out = subprocess.run([exe, str(path), "--intended", "--counter-seeds", "--gpus", "3", "--ordered-sum", "--share-devices"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "rendering on 3 GPU(s)" in out.stdout and "three.png is saved." in out.stdout, out.stdout + out.stderr
+    got = read_png(str(tmp_path / "three.png"))
+    r = Renderer(SceneLoader().loadText(text), options={ffi.OPT_SEMANTICS: 1, ffi.OPT_SEEDING: 1})
+    buf = torch.zeros(80 * 96 * 3, dtype=torch.float32, device="cuda")
+    r.bind_sum_buffer(buf.data_ptr(), buf.numel() * 4)
+    total = None
+    for a, b in ((0, 2), (2, 4), (4, 6)):
+        r.render_range(a, b, clear=True)
+        r.synchronize()
+        total = buf.clone() if total is None else total + buf
+    buf.copy_(total)
+    torch.cuda.synchronize()
+    r.resolve(6)
+    res = r.result()
+    r.close()
+    want = np.empty((80, 96, 4), dtype=np.uint8)
+    ffi.host_lib().pth_result_to_rgba8(res.ctypes.data, 96, 80, want.ctypes.data)
+    assert np.array_equal(got, want)
+    # without the ordered sum a device cannot be used twice
+    bad = subprocess.run([exe, str(path), "--gpus", "2", "--share-devices"], capture_output=True, text=True, timeout=60)
+    assert "ordered sum" in bad.stderr or "present" in bad.stderr
+
+
 def soup(n_tris, n_spheres, seed, degenerate=False):
     """Random triangle soup (+ ellipsoids) around the origin with the camera inside it."""
     rng = np.random.default_rng(seed)
