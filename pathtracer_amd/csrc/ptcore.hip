@@ -397,7 +397,7 @@ int uploadLights(ptc_context* ctx) {
 }
 
 #define TWO_TREES_MAX_PRIMS (1u << 19)  /* builder 3 above this size: one PLOC hierarchy */
-#define N_COUNTERS 24  /* [0..3] nodes / primitives (extension, shadow), [4] shadow rays, [5..6] maxima, [8..14] / [16..22] schedule statistics of the deferred kernel */
+#define N_COUNTERS 24  /* [0..3] nodes / primitives (extension, shadow), [4] shadow rays, [5..6] maxima, [7] shadow rays found occluded (deferred kernel), [8..14] / [16..22] schedule statistics of the deferred kernel */
 #define N_QCOUNT 20
 
 // Trace every bounce of the count0 paths k_generate left in the path state.  Per bounce:

@@ -541,6 +541,10 @@ __global__ __launch_bounds__(BLOCK, DQ_MIN_WAVES) void k_trace_deferred(RenderPa
                 qn -= n;
                 wave_lds_sync();
             }
+            if (ANY && COUNT) {  // occluded rays among the retired ones
+                const unsigned long long occ = __ballot(fin && L.best_ref[tid] != HIT_MISS);
+                if (lane == 0 && occ) atomicAdd(&trav_counters[7], (unsigned long long)__popcll(occ));
+            }
             if (fin) {
                 if (ANY) {
                     if (L.best_ref[tid] != HIT_MISS) {

@@ -26,3 +26,4 @@ for name, base, rays, nodes, prims in (("extension", 8, st.extension_rays, st.no
     print(f"{name}: rays {rays}, nodes/ray {nodes/rays:.2f}, prims/ray {prims/rays:.2f}")
     print(f"  wave iterations {it:.4g} = {it*64/rays:.2f} lane-iterations per ray; lanes owning a ray {owned/it/64:.3f}, visiting a node {node/it/64:.3f}, at a leaf {leaf/it/64:.3f}")
     print(f"  full batches per iteration {full/it:.3f}; partial batches per iteration {part/it:.4f} with {part_items/max(part,1):.1f} tests each; lanes busy in a test batch {(full*64+part_items)/max(full+part,1)/64:.3f}")
+print(f"shadow rays found occluded: {float(c[7]) / max(st.shadow_rays, 1):.3f}")
