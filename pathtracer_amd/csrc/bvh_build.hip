@@ -664,6 +664,101 @@ void sahBuild(const std::vector<Box6>& boxes, const std::vector<uint32_t>& prims
     for (std::thread& t : pool) t.join();
 }
 
+#ifndef BVH_ROTATE_PASSES
+#define BVH_ROTATE_PASSES 4   /* dragon, sweep hierarchy: 6.77 -> 6.72 (1 pass) -> 6.53 (4) -> 6.52 (16) node visits per extension ray; the clustering's is a fixed point */
+#endif
+// Tree rotations on a finished binary tree (leaves 0..n-1, internal nodes n..2n-2): bottom-up, every internal node
+// may swap one child with a grandchild on the other side when that shrinks the box of the child that is rebuilt
+// (the node's own box does not change); `passes` sweeps.  A cheap local repair of what a clustering or a sweep
+// decided early.
+void rotateTree(std::vector<int>& left, std::vector<int>& right, std::vector<Box6>& box, int n, int root, int passes) {
+    if (n < 3) return;
+    auto area = [](const Box6& b) {
+        const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    auto unite = [](const Box6& a, const Box6& b) {
+        Box6 u = a;
+        grow(u, b);
+        return u;
+    };
+    // post-order of the internal nodes
+    std::vector<int> order;
+    order.reserve(n - 1);
+    {
+        std::vector<int> stack{root};
+        while (!stack.empty()) {
+            const int v = stack.back();
+            stack.pop_back();
+            if (v < n) continue;
+            order.push_back(v);
+            stack.push_back(left[v - n]);
+            stack.push_back(right[v - n]);
+        }
+        std::reverse(order.begin(), order.end());  // children before parents
+    }
+    for (int pass = 0; pass < passes; ++pass) {
+        int applied = 0;
+        for (int v : order) {
+            int& L = left[v - n];
+            int& R = right[v - n];
+            // candidates: (which child is rebuilt, which of its children goes up)
+            float best = 0.f;
+            int pick = -1;
+            if (L >= n) {
+                const int A = left[L - n], B = right[L - n];
+                const float old = area(box[L]);
+                const float a0 = area(unite(box[R], box[B])), a1 = area(unite(box[A], box[R]));  // swap R<->A, R<->B
+                if (old - a0 > best) { best = old - a0; pick = 0; }
+                if (old - a1 > best) { best = old - a1; pick = 1; }
+            }
+            if (R >= n) {
+                const int C = left[R - n], D = right[R - n];
+                const float old = area(box[R]);
+                const float a2 = area(unite(box[L], box[D])), a3 = area(unite(box[C], box[L]));  // swap L<->C, L<->D
+                if (old - a2 > best) { best = old - a2; pick = 2; }
+                if (old - a3 > best) { best = old - a3; pick = 3; }
+            }
+            if (pick < 0) continue;
+            ++applied;
+            if (pick == 0) {  // L = (R, B), v = (L, A)
+                const int A = left[L - n];
+                left[L - n] = R;
+                R = A;
+                box[L] = unite(box[left[L - n]], box[right[L - n]]);
+            } else if (pick == 1) {  // L = (A, R), v = (L, B)
+                const int B = right[L - n];
+                right[L - n] = R;
+                R = B;
+                box[L] = unite(box[left[L - n]], box[right[L - n]]);
+            } else if (pick == 2) {  // R = (L, D), v = (C, R)
+                const int C = left[R - n];
+                left[R - n] = L;
+                L = C;
+                box[R] = unite(box[left[R - n]], box[right[R - n]]);
+            } else {  // R = (C, L), v = (D, R)
+                const int D = right[R - n];
+                right[R - n] = L;
+                L = D;
+                box[R] = unite(box[left[R - n]], box[right[R - n]]);
+            }
+        }
+        if (!applied) break;
+        // the post-order of the rotated tree for the next sweep
+        order.clear();
+        std::vector<int> stack{root};
+        while (!stack.empty()) {
+            const int v = stack.back();
+            stack.pop_back();
+            if (v < n) continue;
+            order.push_back(v);
+            stack.push_back(left[v - n]);
+            stack.push_back(right[v - n]);
+        }
+        std::reverse(order.begin(), order.end());
+    }
+}
+
 // Tree over the small primitives of one kind (builder 0: LBVH, 1: PLOC, 2: host SAH sweep); writes the emitted nodes to nodes[node_base..].
 std::string buildKind(hipStream_t s, const Box6* d_boxes, const std::vector<Box6>& boxes, uint32_t kind, float pad, int builder, BvhNode* d_nodes,
                       uint32_t node_base, KindResult& res) {
@@ -708,6 +803,7 @@ std::string buildKind(hipStream_t s, const Box6* d_boxes, const std::vector<Box6
             std::vector<BvhNode> h_nodes;
             int root = 0;
             sahBuild(boxes, small, pad, h_left, h_right, h_box, root);
+            rotateTree(h_left, h_right, h_box, n, root, BVH_ROTATE_PASSES);
             uint32_t depth = 0;
             emitTree(h_left, h_right, h_box, n, root, kind, node_base, h_nodes, order, depth);
             HIPCHK(hipMemcpyAsync(d_nodes + node_base, h_nodes.data(), sizeof(BvhNode) * h_nodes.size(), hipMemcpyHostToDevice, s));
@@ -750,6 +846,7 @@ std::string buildKind(hipStream_t s, const Box6* d_boxes, const std::vector<Box6
             int root = 0;
             std::string err = plocBuild(s, d_boxes, vals_out.p, n, pad, h_left, h_right, h_box, root);
             if (!err.empty()) return err;
+            rotateTree(h_left, h_right, h_box, n, root, BVH_ROTATE_PASSES);
             uint32_t depth = 0;
             emitTree(h_left, h_right, h_box, n, root, kind, node_base, h_nodes, order, depth);
             std::vector<uint32_t> h_sorted(n);
