@@ -934,7 +934,7 @@ float boxArea(const Box6& b) {
     return dx * dy + dy * dz + dz * dx;
 }
 
-bool collapseWide(const std::vector<BvhNode>& bin, std::vector<WideNode>& wide, uint32_t& depth_out) {
+bool collapseWide(const std::vector<BvhNode>& bin, std::vector<WideNode>& wide, uint32_t& depth_out, uint32_t unused_ref = REF_EMPTY_WORD) {
     wide.clear();
     depth_out = 0;
     if (bin.empty()) return false;
@@ -992,7 +992,17 @@ bool collapseWide(const std::vector<BvhNode>& bin, std::vector<WideNode>& wide, 
         std::stable_sort(ch.begin(), ch.end(), [](const WideChild& a, const WideChild& b) { return boxArea(a.box) < boxArea(b.box); });
         WideNode out;
         std::memset(&out, 0, sizeof(out));
-        for (int c = 0; c < 4; ++c) out.child[c] = REF_EMPTY_WORD;
+        // Unused child slots.  For the traversal kernels (`unused_ref` = a leaf of one degenerate triangle) their box is
+        // inside out on every axis, lower plane 255 and upper plane 0: no ray enters it, so the kernels need not look
+        // at the reference to know that a slot is unused -- and should rounding ever let a ray in, the reference
+        // leads to a test that cannot succeed.
+        for (int c = 0; c < 4; ++c) {
+            out.child[c] = unused_ref;
+            if (unused_ref != REF_EMPTY_WORD) {
+                out.qlo_x[c] = out.qlo_y[c] = out.qlo_z[c] = 255;
+                out.qhi_x[c] = out.qhi_y[c] = out.qhi_z[c] = 0;
+            }
+        }
         if (!ch.empty()) {
             Box6 u = ch[0].box;
             for (size_t k = 1; k < ch.size(); ++k) grow(u, ch[k].box);
@@ -1138,9 +1148,13 @@ std::string bvh_build(hipStream_t s, const BvhBuildInput& in, BvhBuildOutput& ou
     HIPCHK(hipMemcpyAsync(out.nodes, top, sizeof(top), hipMemcpyHostToDevice, s));
 
     // 5. geometry in leaf order
-    HIPCHK(hipMalloc((void**)&out.tri_q, std::max<size_t>(T, 1) * 3 * sizeof(float4)));
-    HIPCHK(hipMalloc((void**)&out.tri_mat, std::max<size_t>(T, 1) * sizeof(uint32_t)));
-    HIPCHK(hipMalloc((void**)&out.tri_prim, std::max<size_t>(T, 1) * sizeof(int32_t)));
+    // one triangle more than the scene has: all zeros (no ray hits it), what the unused child slots of the wide nodes refer to
+    HIPCHK(hipMalloc((void**)&out.tri_q, ((size_t)T + 1) * 3 * sizeof(float4)));
+    HIPCHK(hipMalloc((void**)&out.tri_mat, ((size_t)T + 1) * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void**)&out.tri_prim, ((size_t)T + 1) * sizeof(int32_t)));
+    HIPCHK(hipMemsetAsync(out.tri_q + 3 * (size_t)T, 0, 3 * sizeof(float4), s));
+    HIPCHK(hipMemsetAsync(out.tri_mat + T, 0, sizeof(uint32_t), s));
+    HIPCHK(hipMemsetAsync(out.tri_prim + T, 0, sizeof(int32_t), s));
     HIPCHK(hipMalloc((void**)&out.spheres, std::max<size_t>(S, 1) * sizeof(DevSphere)));
     HIPCHK(hipMalloc((void**)&out.sph_mat, std::max<size_t>(S, 1) * sizeof(uint32_t)));
     HIPCHK(hipMalloc((void**)&out.sph_prim, std::max<size_t>(S, 1) * sizeof(int32_t)));
@@ -1180,7 +1194,7 @@ std::string bvh_build(hipStream_t s, const BvhBuildInput& in, BvhBuildOutput& ou
         HIPCHK(hipStreamSynchronize(s));
         std::vector<WideNode> h_wide;
         uint32_t wdepth = 0;
-        if (collapseWide(h_bin, h_wide, wdepth)) {
+        if (collapseWide(h_bin, h_wide, wdepth, MAKE_LEAF(REF_TRI, T, 1u))) {  // slot T: the degenerate triangle after the scene's
             HIPCHK(hipMalloc((void**)&out.wnodes, h_wide.size() * sizeof(WideNode)));
             HIPCHK(hipMemcpyAsync(out.wnodes, h_wide.data(), h_wide.size() * sizeof(WideNode), hipMemcpyHostToDevice, s));
             HIPCHK(hipStreamSynchronize(s));

@@ -33,7 +33,9 @@ static_assert(sizeof(BvhNode) == 64, "BVH node is 64 bytes");
 // Built from the binary tree by pulling grandchildren up (largest box first).  A child
 // box is stored on a grid of the node's own box: plane = origin + q * scale per axis,
 // q in 0..255, scale a power of two (so scale * (1/d) is exact), lower planes rounded
-// down and upper planes up.  Unused children have the reference REF_EMPTY_WORD.
+// down and upper planes up.  Unused child slots have an inside-out box (lower planes 255, upper planes 0) that no
+// ray enters, and refer to a leaf of one all-zero triangle stored after the scene's (the host-side collapse utility
+// of the ABI writes REF_EMPTY_WORD and zero bytes instead; its output is not meant for the kernels).
 //   w0 = (origin.x, origin.y, origin.z, scale.x)
 //   w1 = (scale.y, scale.z, qlo.x[4], qlo.y[4])      [one byte per child]
 //   w2 = (qlo.z[4], qhi.x[4], qhi.y[4], qhi.z[4])

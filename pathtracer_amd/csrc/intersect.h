@@ -374,7 +374,7 @@ __device__ __forceinline__ uint32_t wide_eval(const WideData& nd, const TravRay&
     for (int c = 0; c < 4; ++c) {
         const float tn = fmaxf(max3f(__builtin_fmaf(byte_f(nx, c), sx, bx), __builtin_fmaf(byte_f(ny, c), sy, by), __builtin_fmaf(byte_f(nz, c), sz, bz)), r.tmin);
         const float tf = fminf(min3f(__builtin_fmaf(byte_f(fx, c), sx, bx), __builtin_fmaf(byte_f(fy, c), sy, by), __builtin_fmaf(byte_f(fz, c), sz, bz)), lim);
-        hit[c] = (tn <= tf) & (ref[c] != REF_EMPTY_WORD);  // no short circuit: both sides are cheap, a branch is not
+        hit[c] = tn <= tf;  // an unused child slot has an inside-out box (and a reference to a triangle no ray hits)
         key[c] = hit[c] ? __float_as_uint(tn) : 0xFFFFFFFFu;
     }
     if (SORT) {
