@@ -190,3 +190,24 @@ def test_ranks_sharing_one_gpu(tmp_path, world, ordered):
     assert np.array_equal(got_sums.view(np.uint32), total.cpu().numpy().view(np.uint32))
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     assert got.max() > 0
+
+
+def test_bench_ranks_sharing_one_gpu():
+    """bench.py started plainly with --gpus 2 --share-gpu: the launcher starts two ranks, both render on this box's GPU,
+    the combine goes through gloo; the line reports the one GPU it really used and twice the extension rays of one rank."""
+    import json
+    import subprocess
+    common = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "cornell", "--spp", "8", "--size", "64 64", "--steps", "1", "--warmup", "0",
+              "--no-cpu-baseline"]
+    one = subprocess.run(common, capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run(common + ["--gpus", "2", "--share-gpu"], capture_output=True, text=True, timeout=300)
+    assert two.returncode == 0, two.stderr[-2000:]
+    a, b = json.loads(one.stdout.strip().splitlines()[-1]), json.loads(two.stdout.strip().splitlines()[-1])
+    assert len(two.stdout.strip().splitlines()) == 1  # nothing but the result line on stdout
+    assert a["n_gpus"] == 1 and b["n_gpus"] == 1 and "x2" in b["config"]["parallelism"] and b["config"]["spp_total"] == 16
+    assert b["value"] > 0 and b["scaling"] == "weak"
+    # weak scaling: every rank renders the workload's samples, different ones per rank; the ray counts differ by the
+    # random walks only
+    rays = lambda d: d["value"] * d["ms_per_step"] * d["steps"]
+    assert 1.8 < rays(b) / rays(a) < 2.2
