@@ -6,6 +6,8 @@ recorded image -- through the C ABI, against the CPU oracle.
     8th pixel in x and y, radiance at 2 spp on a window of the full-size frame;
   * the Cornell box with the GGX sphere exactly as bench.py builds it (cornell_ggx);
   * the sample-range split (the multi-GPU partition) on the dragon: [0,3) + [3,8) == [0,8) bit for bit;
+  * the 3840x2160 dragon (one rank's share of the 8-GPU configuration): hits, a rank's sample range against the oracle;
+  * several ranks with the real renderer on this box's one GPU (gloo on host copies), and bench.py's rank path the same way;
   * scene 4/dragonRefract.test (glass triangles in a deep hierarchy), both semantics.
 """
 import os
@@ -78,6 +80,53 @@ def test_dragon_1080p_primary_hits_and_window():
     bm_g, bm_w = block_mean(g, 8), block_mean(w, 8)
     assert np.sqrt(((bm_g - bm_w) ** 2).mean()) / np.abs(bm_w).mean() <= 0.02
     assert st.paths == 1920 * 1080 * 2
+
+
+def test_dragon_4k_primary_hits_window_and_rank_share():
+    """BASELINE configs[4] at its own 3840x2160 (what one rank of the 8-GPU job renders, at 2 + 2 samples instead of
+    512): hit records of every 16th pixel bit-equal to the oracle's; the second rank's share of the sample index space
+    ([2,4), as sample_range gives it) on a window against the oracle rendering the same sample range; the two
+    shares added equal the four samples rendered at once up to the association of the additions, and a continued
+    range equals it bit for bit."""
+    from pathtracer_amd.distributed import sample_range
+    bench = bench_module()
+    scene = SceneLoader().loadText(bench.scene_text_for("dragon_4k", spp_override=4))
+    assert (scene.width, scene.height) == (3840, 2160)
+    r = Renderer(scene, options={_ffi.OPT_SEMANTICS: 1, _ffi.OPT_SEEDING: 1})
+    got = r.primary_hits()
+    want = orc().primary_hits(scene, use_bvh=1, stride=16, threads=16)
+    sub = (slice(0, None, 16), slice(0, None, 16))
+    assert (want["prim"][sub] >= 0).mean() > 0.3
+    assert np.array_equal(got["prim"][sub], want["prim"][sub])
+    for f in ("t", "u", "v"):
+        assert np.array_equal(got[f][sub].view(np.uint32), want[f][sub].view(np.uint32)), f
+    shares = []
+    for rank in (0, 1):
+        j0, j1 = sample_range(rank, 2, 2)
+        r.render_range(j0, j1, clear=True)
+        r.synchronize()
+        shares.append(r.sums().copy())
+    r.render_range(0, 4, clear=True)
+    r.synchronize()
+    whole = r.sums().copy()
+    r.render_range(0, 2, clear=True)
+    r.render_range(2, 4, clear=False)
+    r.synchronize()
+    continued = r.sums().copy()
+    r.close()
+    # the same samples whatever the partition: continuing a range is bit-identical to one range; two buffers added
+    # afterwards differ from it by the association of the additions only ((s0+s1)+(s2+s3) against ((s0+s1)+s2)+s3)
+    assert np.array_equal(continued.view(np.uint32), whole.view(np.uint32))
+    assert np.allclose(shares[0] + shares[1], whole, rtol=2e-7 * 4, atol=0, equal_nan=True)  # a few dozen GGX grazing-angle NaNs, as in the reference
+    x0, y0, x1, y1 = 1600, 880, 1920, 1080
+    wsum, _, _ = orc().render(scene, semantics=1, seeding=1, use_bvh=1, threads=16, window=(x0, y0, x1, y1), spp_begin=2, spp_end=4)
+    g, w = shares[1][y0:y1, x0:x1].copy(), wsum[y0:y1, x0:x1].copy()
+    assert close_fraction(g, w) >= 0.99
+    bad = ~(np.isfinite(g) & np.isfinite(w))  # the GGX terms' grazing-angle NaNs (both sides have them; the dragon's head is in the window)
+    assert bad.mean() < 1e-3
+    g[bad] = w[bad] = 0.0
+    bm_g, bm_w = block_mean(g, 8), block_mean(w, 8)
+    assert np.sqrt(((bm_g - bm_w) ** 2).mean()) / np.abs(bm_w).mean() <= 0.02
 
 
 @pytest.mark.parametrize("seeding", [0, 1])
