@@ -197,7 +197,8 @@ enum {
     /* 1 = before the extension traversal of every bounce after the first, the live paths are reordered by
      * (cell of the ray origin on a 128^3 grid, direction octant): a radix sort of 24-bit keys plus one pass
      * that moves the packed state.  Results do not depend on it.  Default 0: on the dragon the more coherent
-     * traversal saves less than the sort costs. */
+     * traversal saves less than the sort costs (extension traversal -13 %, the sort and the move 42 ms per
+     * 1080p x 256 spp frame). */
     PTC_OPT_SORT_RAYS = 13
 };
 
