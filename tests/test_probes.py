@@ -20,7 +20,7 @@ import pytest
 from test_golden_fixtures import FIX, mk
 from util import ROOT
 
-# |gpu - oracle| <= ATOL + RTOL * |oracle| per component, for every input (the measured maxima are about half of these:
+# |gpu - oracle| <= ATOL + RTOL * |oracle| per component, for every input (with margin over the measured maxima:
 # the test writes them to gpurun_out/probe_errors.json)
 SHADE_BOUNDS = {0: (2e-7, 2e-6), 1: (1e-6, 1e-5), 2: (5e-7, 2e-6), 3: (4e-6, 0.0), 4: (4e-6, 0.0)}
 SHADE_NAMES = {0: "phongBRDF", 1: "ggxBRDF", 2: "ggxPDF", 3: "Phong-sampled direction", 4: "GGX-sampled direction"}
