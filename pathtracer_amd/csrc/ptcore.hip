@@ -98,7 +98,7 @@ struct ptc_context {
     uint32_t contrib_samples = 0;
     uint32_t* hitq = nullptr;                   // paths of this bounce that hit something
     uint32_t* gatherq = nullptr;                // segments of this bounce whose radiance waits for the light terms
-    uint32_t* qcount = nullptr;                 // two groups {hit, next, shadow, extend work, shadow work, gather} used alternately, [16] generate
+    uint32_t* qcount = nullptr;                 // two groups {hit, next, shadow, extend work, shadow work, gather} used alternately
     uint32_t resident_waves = 6144;
     unsigned long long* counters = nullptr;     // [0..3] traversal nodes/prims (extension, shadow), [4] shadow rays
     uint32_t* h_count = nullptr;                // pinned
@@ -509,14 +509,11 @@ int renderBatches(ptc_context* ctx, RenderParams& rp, int32_t j0, int32_t j1, ui
         rp.inv_batch_samples = 1.0 / (double)ns;
         const uint32_t n_paths = ns * ctx->npix_pad;
         const int seedL = rp.seeding == 0 ? 1 : 0;  // reference order: result += radiance per segment
-        CHK(hipMemsetAsync(ctx->qcount + 16, 0, sizeof(uint32_t), ctx->stream));
         {
             Timed t(ctx, 3);
-            wf_generate(ctx->stream, rp, ctx->ps, ctx->npix_pad, n_paths, (uint32_t)ja, ctx->acc, ctx->segctr, ctx->pixseed, seedL, ctx->qcount + 16);
+            wf_generate(ctx->stream, rp, ctx->ps, ctx->npix_pad, n_paths, (uint32_t)ja, ctx->acc, ctx->segctr, ctx->pixseed, seedL);
         }
-        CHK(hipMemcpyAsync(ctx->h_count, ctx->qcount + 16, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-        CHK(hipStreamSynchronize(ctx->stream));
-        const uint32_t count0 = *ctx->h_count;
+        const uint32_t count0 = ns * rp.width * rp.height;  // the padding pixels' paths are not in the packed state
         ctx->stats.paths += count0;
         const int rc = runBounces(ctx, rp, sc, count0, (uint32_t)ja);
         if (rc) return rc;
@@ -940,11 +937,10 @@ int ptc_primary_hits(ptc_context* ctx, uint32_t width, uint32_t height, PtcHitRe
     const DevScene sc = deviceScene(ctx);
     CHK(hipMemsetAsync(ctx->qcount, 0, N_QCOUNT * sizeof(uint32_t), ctx->stream));
     CHK(hipMemsetAsync(ctx->ps.hit_ref, 0xFF, (size_t)ctx->npix_pad * sizeof(int32_t), ctx->stream));  // HIT_MISS
-    wf_generate(ctx->stream, rp, ctx->ps, ctx->npix_pad, ctx->npix_pad, 0u, ctx->acc, ctx->segctr, ctx->pixseed, 0, ctx->qcount + 16);
-    CHK(hipMemcpyAsync(ctx->h_count, ctx->qcount + 16, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    CHK(hipStreamSynchronize(ctx->stream));
-    wf_extend(ctx->stream, rp, sc, ctx->ps, *ctx->h_count, ctx->qcount + 3, ctx->resident_waves, true, false, ctx->counters);
-    wf_hit_records(ctx->stream, rp, sc, ctx->ps, *ctx->h_count, ctx->d_hits);
+    wf_generate(ctx->stream, rp, ctx->ps, ctx->npix_pad, ctx->npix_pad, 0u, ctx->acc, ctx->segctr, ctx->pixseed, 0);
+    const uint32_t n_rays = width * height;
+    wf_extend(ctx->stream, rp, sc, ctx->ps, n_rays, ctx->qcount + 3, ctx->resident_waves, true, false, ctx->counters);
+    wf_hit_records(ctx->stream, rp, sc, ctx->ps, n_rays, ctx->d_hits);
     CHK(hipMemcpyAsync(out, ctx->d_hits, (size_t)width * height * sizeof(PtcHitRecord), hipMemcpyDeviceToHost, ctx->stream));
     CHK(hipStreamSynchronize(ctx->stream));
     CHK(hipGetLastError());

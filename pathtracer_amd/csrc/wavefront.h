@@ -10,7 +10,7 @@
 #include "device_scene.h"
 
 void wf_generate(hipStream_t s, const RenderParams& rp, const PathState& ps, uint32_t npix_pad, uint32_t n_paths, uint32_t sample_begin,
-                 const float* acc, uint32_t* segctr, uint32_t* pixseed /* npix_pad words of scratch */, int seed_L_from_acc, uint32_t* qcount);
+                 const float* acc, uint32_t* segctr, uint32_t* pixseed /* npix_pad words of scratch */, int seed_L_from_acc);
 // closest hits of the live paths (entries [0, count) of the packed path state); `work_counter`
 // is a zeroed device word the refilling waves reserve their spans from; `coherent` = camera rays
 void wf_extend(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, uint32_t count, uint32_t* work_counter,

@@ -92,6 +92,21 @@ __device__ __forceinline__ bool pixel_of(const RenderParams& rp, uint32_t pix, u
     return x < rp.width && y < rp.height;
 }
 
+// Number of image pixels among the padded pixel numbers below tile `tile_global` (= pix >> 6), and the width and
+// height of that tile's part of the image (0 x 0 ... 8 x 8).  Only the last column and the last row of 64x64 blocks
+// are cut by the image border.
+__device__ __forceinline__ uint32_t pixels_before_tile(const RenderParams& rp, uint32_t tile_global, uint32_t& tw, uint32_t& th) {
+    const uint32_t blocks_x = (rp.width + 63u) >> 6;
+    const uint32_t tile = tile_global & 63u, block = tile_global >> 6;
+    uint32_t bx;
+    const uint32_t by = div_by(block, blocks_x, rp.inv_tiles_x, bx);
+    const uint32_t vw = min(64u, rp.width - (bx << 6)), vh = min(64u, rp.height - (by << 6));  // the block's part of the image
+    const uint32_t x0 = (tile & 7u) << 3, y0 = (tile >> 3) << 3;                               // the tile's corner in the block
+    tw = vw > x0 ? min(8u, vw - x0) : 0u;
+    th = vh > y0 ? min(8u, vh - y0) : 0u;
+    return (by << 6) * rp.width + (bx << 6) * vh + min(y0, vh) * vw + min(x0, vw) * th;
+}
+
 // Reserve one queue position for every thread with keep=true and return it.  Wave64
 // ballot + popcount give the position inside the wave, the waves' counts meet in LDS
 // and ONE atomic per block reserves the block's span (a per-wave atomic on the single
@@ -242,20 +257,22 @@ __global__ __launch_bounds__(BLOCK) void k_pixel_seeds(RenderParams rp, uint32_t
 
 __global__ __launch_bounds__(GEN_BLOCK) void k_generate(RenderParams rp, PathState ps, uint32_t npix_pad, uint32_t n_paths, uint32_t sample_begin,
                                                     const float* __restrict__ acc, uint32_t* __restrict__ segctr, const uint32_t* __restrict__ pixseed,
-                                                    int seed_L_from_acc, uint32_t* __restrict__ qcount) {
+                                                    int seed_L_from_acc) {
     const uint32_t p = blockIdx.x * GEN_BLOCK + threadIdx.x;
-    bool valid = p < n_paths;
+    if (p >= n_paths) return;  // whole waves: the number of paths is a multiple of 64
     uint32_t x = 0, y = 0, pix = 0, j = 0;
-    if (valid) {
-        path_split(rp, p, pix, j);
-        j += sample_begin;
-        valid = pixel_of(rp, pix, x, y);
-    }
+    path_split(rp, p, pix, j);
+    const bool valid = pixel_of(rp, pix, x, y);
     // The 64 paths of a wave are one sample of one 8x8 tile (path_number): telling the compiler so turns the
-    // jump-ahead of the jitter stream below, a loop of 32-bit multiplies, into scalar code.
-    j = (uint32_t)__builtin_amdgcn_readfirstlane((int)j);
-    // live paths are kept packed: this one's state goes to position `at`
-    const uint32_t at = queue_reserve(valid, qcount);
+    // jump-ahead of the jitter stream below, a loop of 32-bit multiplies, and the position below into scalar code.
+    const uint32_t js = (uint32_t)__builtin_amdgcn_readfirstlane((int)j);  // sample within the batch
+    j = js + sample_begin;
+    // Live paths are kept packed, in path-number order: this one's state goes to position `at`, the number of
+    // valid paths below it.  Computed, not reserved from a counter: the rate of atomics on one word (about 88
+    // blocks per microsecond) would bound this kernel, and the host knows the count without reading it back.
+    uint32_t tw, th;
+    const uint32_t before = pixels_before_tile(rp, (uint32_t)__builtin_amdgcn_readfirstlane((int)(pix >> 6)), tw, th);
+    const uint32_t at = before * rp.batch_samples + js * (tw * th) + ((p >> 3) & 7u) * tw + (p & 7u);
     if (valid) {
         const PtcConfig& cf = rp.cf;
         const uint32_t index = x * rp.height + y;  // PinholeCamera.cu:23
@@ -1592,10 +1609,10 @@ __global__ __launch_bounds__(BLOCK) void k_eval_shading(int fn, uint32_t n, cons
 static inline uint32_t blocks_for(uint64_t n, uint32_t block = BLOCK) { return (uint32_t)((n + block - 1) / block); }
 
 void wf_generate(hipStream_t s, const RenderParams& rp, const PathState& ps, uint32_t npix_pad, uint32_t n_paths, uint32_t sample_begin,
-                 const float* acc, uint32_t* segctr, uint32_t* pixseed, int seed_L_from_acc, uint32_t* qcount) {
+                 const float* acc, uint32_t* segctr, uint32_t* pixseed, int seed_L_from_acc) {
     hipLaunchKernelGGL(k_pixel_seeds, dim3(blocks_for(npix_pad)), dim3(BLOCK), 0, s, rp, npix_pad, pixseed);
     hipLaunchKernelGGL(k_generate, dim3(blocks_for(n_paths, GEN_BLOCK)), dim3(GEN_BLOCK), 0, s, rp, ps, npix_pad, n_paths, sample_begin, acc, segctr, pixseed,
-                       seed_L_from_acc, qcount);
+                       seed_L_from_acc);
 }
 
 // Grid and per-wave span of a traversal launch over (at most) n rays: enough waves to

@@ -44,7 +44,7 @@ def sums_close(scene, **kw):
     return got
 
 
-@pytest.mark.parametrize("size", ["1 1", "7 5", "37 23", "65 9", "8 64"])
+@pytest.mark.parametrize("size", ["1 1", "7 5", "37 23", "65 9", "8 64", "64 64", "130 67", "129 128"])
 def test_ragged_image_sizes(size):
     """Sizes that are not multiples of the 8x8 tile a wave renders (down to one pixel)."""
     scene = SceneLoader().loadText(override_scene_text(scene_text("scene3/cornellRR.test"), size=size, spp="3"))
