@@ -331,6 +331,38 @@ def test_many_coincident_primitives(builder):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
+def test_more_primitives_than_get_two_hierarchies():
+    """540 000 triangles, more than the 2^19 primitives up to which closest-hit and any-hit rays get a hierarchy
+    each (beyond it one clustered hierarchy serves both): the default builder against brute force."""
+    import ctypes as C
+    scene = soup(n_tris=6000, n_spheres=0, seed=21)
+    n, size = len(scene.triangles), C.sizeof(_ffi.Triangle)
+    raw = np.frombuffer(scene.triangles, dtype=np.uint8).reshape(n, size)
+    copies = 90
+    out = np.tile(raw, (copies, 1))
+    corners = out[:, :36].copy().view(np.float32).reshape(copies, n, 3, 3)  # v1, v2, v3 lead the record
+    shift = np.random.default_rng(3).uniform(-3, 3, (copies, 1, 1, 3)).astype(np.float32)
+    shift[0] = 0  # the first copy stays around the camera
+    corners += shift
+    out[:, :36] = corners.reshape(copies * n, 9).view(np.uint8)
+    scene.triangles = (_ffi.Triangle * len(out)).from_buffer_copy(out.tobytes())
+    assert len(scene.triangles) > 1 << 19
+    b = Renderer(scene, options={_ffi.OPT_BRUTE_FORCE: 1})
+    want_hits = b.primary_hits()
+    b.run()
+    want = b.sums()
+    b.close()
+    assert (want_hits["prim"] >= 0).mean() > 0.5
+    r = Renderer(scene)
+    hits = r.primary_hits()
+    r.run()
+    got = r.sums()
+    r.close()
+    for f in ("prim", "t", "u", "v"):
+        assert np.array_equal(hits[f].view(np.uint32), want_hits[f].view(np.uint32)), f
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
 @pytest.mark.parametrize("far", ["1e30", "3e38"])
 def test_extreme_coordinates_against_brute_force(far):
     """A small soup in front of a backdrop triangle with astronomically large coordinates.  With
