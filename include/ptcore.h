@@ -274,7 +274,11 @@ int  ptc_read_result(ptc_context* ctx, float* rgb_out);
 int  ptc_read_sum(ptc_context* ctx, float* rgb_out);
 /* Build-only: let the caller own the device memory of the radiance sums
  * (width*height*3 floats), e.g. a tensor that a collective then reduces.
- * NULL returns to the context's own buffer. */
+ * NULL returns to the context's own buffer.  The context reads, clears and
+ * writes the buffer on ITS stream (ptc_set_stream): work of another stream
+ * that touches it -- the fill that created it, a copy or a sum read from it --
+ * has to be complete before the next ptc_render* call and must not start
+ * before ptc_synchronize (or an event wait on the context's stream). */
 int  ptc_bind_sum_buffer(ptc_context* ctx, void* device_ptr, size_t bytes);
 /* Build-only: run on the caller's HIP stream (hipStream_t as void*). */
 int  ptc_set_stream(ptc_context* ctx, void* hip_stream);

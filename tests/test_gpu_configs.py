@@ -225,12 +225,14 @@ def test_ranks_sharing_one_gpu(tmp_path, world, ordered):
     scene = SceneLoader().loadText(override_scene_text(scene_text("scene3/cornellRR.test"), size="96 80", spp=str(spp * world), maxdepth="6"))
     r = Renderer(scene, options={_ffi.OPT_SEMANTICS: 1, _ffi.OPT_SEEDING: 1})
     buf = torch.zeros(80 * 96 * 3, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
     r.bind_sum_buffer(buf.data_ptr(), buf.numel() * 4)
     total = None
     for g in range(world):
         r.render_range(g * spp, (g + 1) * spp, clear=True)
         r.synchronize()
         total = buf.clone() if total is None else total + buf
+        torch.cuda.synchronize()  # torch's stream has read the sums before the next range clears them on the renderer's stream
     buf.copy_(total)
     torch.cuda.synchronize()
     r.resolve(spp * world)

@@ -237,12 +237,14 @@ def test_command_line_several_contexts_on_one_device(tmp_path):
     got = read_png(str(tmp_path / "three.png"))
     r = Renderer(SceneLoader().loadText(text), options={ffi.OPT_SEMANTICS: 1, ffi.OPT_SEEDING: 1})
     buf = torch.zeros(80 * 96 * 3, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
     r.bind_sum_buffer(buf.data_ptr(), buf.numel() * 4)
     total = None
     for a, b in ((0, 2), (2, 4), (4, 6)):
         r.render_range(a, b, clear=True)
         r.synchronize()
         total = buf.clone() if total is None else total + buf
+        torch.cuda.synchronize()  # torch's stream has read the sums before the next range clears them on the renderer's stream
     buf.copy_(total)
     torch.cuda.synchronize()
     r.resolve(6)
