@@ -127,6 +127,7 @@ struct RenderParams {
     int32_t seeding;          // 0 reference, 1 counter
     int32_t cull_zero;
     uint32_t init_L;          // this bounce gives every path's radiance sum its first value (camera segments): written, not added to
+    uint32_t camera_rays;     // the segments of this bounce are camera segments: origin = the eye, one record (direction | seed) per path
     int32_t brute_force;
     uint32_t samples_per_path;  // shadow-ray samples per segment (integrator dependent)
     uint32_t group_hits;        // group the hits of a bounce by shading class (mixed scenes)

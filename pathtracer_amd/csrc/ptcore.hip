@@ -418,6 +418,7 @@ int runBounces(ptc_context* ctx, const RenderParams& rp_frame, const DevScene& s
     while (count > 0 && bounce < max_iters) {
         // camera segments of a batch whose sums k_generate did not seed: this bounce writes them
         rp.init_L = (bounce == 0 && first_is_camera && rp.seeding != 0) ? 1u : 0u;
+        rp.camera_rays = (bounce == 0 && first_is_camera) ? 1u : 0u;
         uint32_t* grp = ctx->qcount + 8 * (bounce & 1u);  // {hit count, next count, shadow-ray count, extend work, shadow work, gather count}
         CHK(hipMemsetAsync(grp, 0, 6 * sizeof(uint32_t), ctx->stream));
         if (ctx->sort_rays && bounce >= 1u && count >= 65536u && !ctx->no_alloc) {
@@ -939,6 +940,7 @@ int ptc_primary_hits(ptc_context* ctx, uint32_t width, uint32_t height, PtcHitRe
     CHK(hipMemsetAsync(ctx->ps.hit_ref, 0xFF, (size_t)ctx->npix_pad * sizeof(int32_t), ctx->stream));  // HIT_MISS
     wf_generate(ctx->stream, rp, ctx->ps, ctx->npix_pad, ctx->npix_pad, 0u, ctx->acc, ctx->segctr, ctx->pixseed, 0);
     const uint32_t n_rays = width * height;
+    rp.camera_rays = 1u;
     wf_extend(ctx->stream, rp, sc, ctx->ps, n_rays, ctx->qcount + 3, ctx->resident_waves, true, false, ctx->counters);
     wf_hit_records(ctx->stream, rp, sc, ctx->ps, n_rays, ctx->d_hits);
     CHK(hipMemcpyAsync(out, ctx->d_hits, (size_t)width * height * sizeof(PtcHitRecord), hipMemcpyDeviceToHost, ctx->stream));

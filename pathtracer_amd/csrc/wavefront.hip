@@ -243,6 +243,18 @@ __device__ __forceinline__ uint32_t segment_seed(const RenderParams& rp, uint32_
     return tea16(key0, (sample << 12) | bounce);
 }
 
+// (origin | seed) and (direction | depth) of the segment at position `at` of the path state.  Camera segments all
+// start at the eye with depth 0, so k_generate writes one record per path for them, (direction | seed), and not two.
+__device__ __forceinline__ void load_segment(const RenderParams& rp, const PathState& ps, uint32_t at, float4& o4, float4& d4) {
+    d4 = ps.d_depth[at];
+    if (rp.camera_rays) {
+        o4 = make_float4(rp.cf.eye.x, rp.cf.eye.y, rp.cf.eye.z, d4.w);
+        d4.w = u2f(0u);
+    } else {
+        o4 = ps.o_seed[at];
+    }
+}
+
 // ---------------------------------------------------------------- generate --
 #define GEN_CHUNKS 4   /* chunks of GEN_BLOCK queue entries per block of k_compact_hits */
 
@@ -288,8 +300,7 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_generate(RenderParams rp, PathSta
         const float aby = cf.tanHFov.y * (py - cf.hSize.y) / cf.hSize.y;
         const vec3 dir = normalize(abx * P3v(cf.u) + aby * P3v(cf.v) - P3v(cf.w));  // :51
         const uint32_t seed = segment_seed(rp, key0, j, 0u, segctr, pix);
-        ps.o_seed[at] = make_float4(cf.eye.x, cf.eye.y, cf.eye.z, u2f(seed));
-        ps.d_depth[at] = make_float4(dir.x, dir.y, dir.z, u2f(0u));
+        ps.d_depth[at] = make_float4(dir.x, dir.y, dir.z, u2f(seed));  // origin = the eye, depth 0: load_segment
         ps.pid[at] = p;
         // the path's radiance sum: seeded with the pixel's running sum (reference order of additions), or left to
         // the first bounce, which writes it (RenderParams::init_L) -- every camera segment ends in exactly one of a
@@ -357,7 +368,8 @@ __global__ __launch_bounds__(BLOCK) void k_extend(RenderParams rp, DevScene sc, 
             const uint32_t idx = wave_fetch(w, !active, work_counter, wave_chunk, count);
             if (idx != 0xFFFFFFFFu) {
                 p = idx;
-                const float4 o4 = ps.o_seed[p], d4 = ps.d_depth[p];
+                float4 o4, d4;
+                load_segment(rp, ps, p, o4, d4);
                 active = trav_init(sc, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), rp.cf.epsilon, PT_RAY_MAX, r, sp, cur, best);
                 if (!active) {  // NaN direction or empty scene: a miss
                     ps.hit_t[p] = best.t;
@@ -396,7 +408,8 @@ __global__ __launch_bounds__(BLOCK) void k_extend_static(RenderParams rp, DevSce
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= count) return;
     const uint32_t p = i;
-    const float4 o4 = ps.o_seed[p], d4 = ps.d_depth[p];
+    float4 o4, d4;
+    load_segment(rp, ps, p, o4, d4);
     ClosestHit best;
     TravCounters cnt = {0u, 0u};
     traverse_simple<false, COUNT>(sc, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), rp.cf.epsilon, PT_RAY_MAX, stack + threadIdx.x, best, cnt);
@@ -586,8 +599,7 @@ __global__ __launch_bounds__(BLOCK, DQ_MIN_WAVES) void k_trace_deferred(RenderPa
                         d4.w = o4.w;     // tmax
                     } else {
                         p = idx;
-                        o4 = ps.o_seed[p];
-                        d4 = ps.d_depth[p];
+                        load_segment(rp, ps, p, o4, d4);
                         d4.w = PT_RAY_MAX;
                     }
                     o4.w = rp.cf.epsilon;
@@ -699,7 +711,8 @@ __global__ __launch_bounds__(BLOCK) void k_extend_brute(RenderParams rp, DevScen
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= count) return;
     const uint32_t p = i;
-    const float4 o4 = ps.o_seed[p], d4 = ps.d_depth[p];
+    float4 o4, d4;
+    load_segment(rp, ps, p, o4, d4);
     ClosestHit best;
     brute_force<false>(sc, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), rp.cf.epsilon, PT_RAY_MAX, best);
     ps.hit_t[p] = best.t;
@@ -1337,7 +1350,9 @@ __global__ __launch_bounds__(SURF_BLOCK_MANY, SURF_WAVES) void k_surface(RenderP
         at_state = queue[i];
         p = ps.pid[at_state];
         // camera segments: throughput 1, segment 0 (k_generate does not write them)
-        const float4 o4 = ps.o_seed[at_state], d4 = ps.d_depth[at_state], t4 = first_bounce ? make_float4(1.f, 1.f, 1.f, u2f(0u)) : ps.thr[at_state];
+        float4 o4, d4;
+        load_segment(rp, ps, at_state, o4, d4);
+        const float4 t4 = first_bounce ? make_float4(1.f, 1.f, 1.f, u2f(0u)) : ps.thr[at_state];
         sg.o = mk3(o4.x, o4.y, o4.z);
         sg.d = mk3(d4.x, d4.y, d4.z);
         sg.thr = mk3(t4.x, t4.y, t4.z);
@@ -1549,7 +1564,8 @@ __global__ __launch_bounds__(BLOCK) void k_hit_records(RenderParams rp, DevScene
     if (ref != HIT_MISS) {
         rec.t = ps.hit_t[i];
         if (ref >= 0) {
-            const float4 o4 = ps.o_seed[i], d4 = ps.d_depth[i];
+            float4 o4, d4;
+            load_segment(rp, ps, i, o4, d4);
             const float4* q = sc.tri_q + 3 * (size_t)ref;
             const Cand c = tri_candidate(q[0], q[1], q[2], mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), 0.f, PT_RAY_MAX);
             rec.u = c.u;
