@@ -123,7 +123,10 @@ enum {
     PTC_ERR_INTEGRATOR   = -2,  /* unknown integrator name                     */
     PTC_ERR_DEVICE       = -3,  /* HIP error (message has the HIP string)      */
     PTC_ERR_UNSUPPORTED  = -4,  /* scene uses a feature outside the built path */
-    PTC_ERR_NOT_BUILT    = -5   /* render before ptc_build                     */
+    PTC_ERR_NOT_BUILT    = -5,  /* render before ptc_build                     */
+    PTC_ERR_HOST         = -6   /* host-side failure (out of memory, a thread
+                                   that could not start): no exception leaves
+                                   the library                                 */
 };
 
 /* ---------------------------------------------------------------- options -- */

@@ -22,6 +22,7 @@
 #include <cstring>
 #include <atomic>
 #include <condition_variable>
+#include <exception>
 #include <mutex>
 #include <system_error>
 #include <thread>
@@ -616,7 +617,8 @@ void sahBuild(const std::vector<Box6>& boxes, const std::vector<uint32_t>& prims
     std::condition_variable cv;
     std::vector<Job> shared{{0, n, root}};
     int pending = 1;  // jobs in `shared` or being split by a thread (under `mu`)
-    auto worker = [&]() {
+    std::exception_ptr failure;  // the first exception of any thread (under `mu`); rethrown by the caller's thread
+    auto work = [&]() {
         std::vector<int> tmp;
         std::vector<float> suffix;
         std::vector<Job> local;
@@ -624,8 +626,8 @@ void sahBuild(const std::vector<Box6>& boxes, const std::vector<uint32_t>& prims
             Job j;
             {
                 std::unique_lock<std::mutex> lock(mu);
-                cv.wait(lock, [&] { return !shared.empty() || pending == 0; });
-                if (shared.empty()) return;
+                cv.wait(lock, [&] { return failure || !shared.empty() || pending == 0; });
+                if (failure || shared.empty()) return;
                 j = shared.back();
                 shared.pop_back();
             }
@@ -652,6 +654,16 @@ void sahBuild(const std::vector<Box6>& boxes, const std::vector<uint32_t>& prims
             }
         }
     };
+    // an exception in one thread (out of memory) ends the build for all of them instead of ending the process
+    auto worker = [&]() {
+        try {
+            work();
+        } catch (...) {
+            std::lock_guard<std::mutex> lock(mu);
+            if (!failure) failure = std::current_exception();
+            cv.notify_all();
+        }
+    };
     const unsigned hw = std::thread::hardware_concurrency();
     const int n_threads = n < 2 * SHARE_MIN ? 1 : (int)std::min<unsigned>(8u, std::max<unsigned>(1u, hw));
     std::vector<std::thread> pool;
@@ -662,6 +674,7 @@ void sahBuild(const std::vector<Box6>& boxes, const std::vector<uint32_t>& prims
     }
     worker();
     for (std::thread& t : pool) t.join();
+    if (failure) std::rethrow_exception(failure);
 }
 
 #ifndef BVH_ROTATE_PASSES

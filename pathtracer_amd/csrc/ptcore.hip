@@ -586,6 +586,17 @@ int enter(ptc_context* ctx) {
     if (e != hipSuccess) return fail(ctx, PTC_ERR_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
     return PTC_OK;
 }
+// An exception (std::bad_alloc from a host container, a thread that could not start ...) must not leave through the
+// C ABI: every entry point is a function-try-block that ends here.
+int caught(ptc_context* ctx, const char* what) noexcept {
+    try {
+        const std::string msg = std::string("host-side failure: ") + what;
+        if (ctx) ctx->error = msg;
+        else g_create_error = msg;
+    } catch (...) {
+    }
+    return PTC_ERR_HOST;
+}
 #define ENTER()                  \
     do {                         \
         int rc_ = enter(ctx);    \
@@ -596,7 +607,7 @@ int enter(ptc_context* ctx) {
 
 extern "C" {
 
-int ptc_create(int device_ordinal, ptc_context** out) {
+int ptc_create(int device_ordinal, ptc_context** out) try {
     if (!out) {
         g_create_error = "ptc_create: null output pointer";
         return PTC_ERR_INVALID;
@@ -645,6 +656,10 @@ int ptc_create(int device_ordinal, ptc_context** out) {
     }
     *out = ctx;
     return PTC_OK;
+} catch (const std::exception& e) {
+    return caught(nullptr, e.what());
+} catch (...) {
+    return caught(nullptr, "unknown exception");
 }
 
 int ptc_destroy(ptc_context* ctx) {
@@ -673,16 +688,20 @@ int ptc_destroy(ptc_context* ctx) {
 
 const char* ptc_last_error(const ptc_context* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
 
-int ptc_set_config(ptc_context* ctx, const PtcConfig* cfg) {
+int ptc_set_config(ptc_context* ctx, const PtcConfig* cfg) try {
     ENTER();
     if (!cfg) return fail(ctx, PTC_ERR_INVALID, "null config");
     ctx->cfg = *cfg;
     ctx->next_event_est = cfg->next_event_est;
     ctx->have_cfg = true;
     return PTC_OK;
+} catch (const std::exception& e) {
+    return caught(ctx, e.what());
+} catch (...) {
+    return caught(ctx, "unknown exception");
 }
 
-int ptc_set_integrator(ptc_context* ctx, const char* name) {
+int ptc_set_integrator(ptc_context* ctx, const char* name) try {
     ENTER();
     if (!name) return fail(ctx, PTC_ERR_INVALID, "null integrator name");
     for (int i = 0; i < 5; ++i)
@@ -691,9 +710,13 @@ int ptc_set_integrator(ptc_context* ctx, const char* name) {
             return PTC_OK;
         }
     return fail(ctx, PTC_ERR_INTEGRATOR, std::string("Doesn't support the integrator ") + name);
+} catch (const std::exception& e) {
+    return caught(ctx, e.what());
+} catch (...) {
+    return caught(ctx, "unknown exception");
 }
 
-int ptc_set_params(ptc_context* ctx, uint32_t light_samples, uint32_t light_stratify, uint32_t next_event_est, uint32_t sampling_method, int32_t spp) {
+int ptc_set_params(ptc_context* ctx, uint32_t light_samples, uint32_t light_stratify, uint32_t next_event_est, uint32_t sampling_method, int32_t spp) try {
     ENTER();
     if (spp < 0) return fail(ctx, PTC_ERR_INVALID, "samples_per_pixel must be >= 0");
     if (light_samples > (1u << 20)) return fail(ctx, PTC_ERR_INVALID, "light_samples too large");
@@ -703,27 +726,39 @@ int ptc_set_params(ptc_context* ctx, uint32_t light_samples, uint32_t light_stra
     ctx->sampling_method = sampling_method;
     ctx->spp = spp;
     return PTC_OK;
+} catch (const std::exception& e) {
+    return caught(ctx, e.what());
+} catch (...) {
+    return caught(ctx, "unknown exception");
 }
 
-int ptc_set_triangles(ptc_context* ctx, const PtcTriangle* tris, size_t n) {
+int ptc_set_triangles(ptc_context* ctx, const PtcTriangle* tris, size_t n) try {
     ENTER();
     if (n && !tris) return fail(ctx, PTC_ERR_INVALID, "null triangle array");
     if (n > (1u << 27) - 1) return fail(ctx, PTC_ERR_INVALID, "too many triangles");
     ctx->tris.assign(tris, tris + n);
     ctx->built = false;
     return PTC_OK;
+} catch (const std::exception& e) {
+    return caught(ctx, e.what());
+} catch (...) {
+    return caught(ctx, "unknown exception");
 }
 
-int ptc_set_spheres(ptc_context* ctx, const PtcSphere* sph, size_t n) {
+int ptc_set_spheres(ptc_context* ctx, const PtcSphere* sph, size_t n) try {
     ENTER();
     if (n && !sph) return fail(ctx, PTC_ERR_INVALID, "null sphere array");
     if (n > (1u << 27) - 1) return fail(ctx, PTC_ERR_INVALID, "too many spheres");
     ctx->spheres.assign(sph, sph + n);
     ctx->built = false;
     return PTC_OK;
+} catch (const std::exception& e) {
+    return caught(ctx, e.what());
+} catch (...) {
+    return caught(ctx, "unknown exception");
 }
 
-int ptc_set_lights(ptc_context* ctx, const PtcPointLight* pl, size_t np, const PtcDirectionalLight* dl, size_t nd, const PtcQuadLight* ql, size_t nq) {
+int ptc_set_lights(ptc_context* ctx, const PtcPointLight* pl, size_t np, const PtcDirectionalLight* dl, size_t nd, const PtcQuadLight* ql, size_t nq) try {
     ENTER();
     if ((np && !pl) || (nd && !dl) || (nq && !ql)) return fail(ctx, PTC_ERR_INVALID, "null light array");
     if (np + nd > 4096 || nq > 4096) return fail(ctx, PTC_ERR_INVALID, "too many lights");
@@ -731,17 +766,25 @@ int ptc_set_lights(ptc_context* ctx, const PtcPointLight* pl, size_t np, const P
     ctx->dlights.assign(dl, dl + nd);
     ctx->qlights.assign(ql, ql + nq);
     return uploadLights(ctx);  // device copies are made here, so that no render call has to allocate
+} catch (const std::exception& e) {
+    return caught(ctx, e.what());
+} catch (...) {
+    return caught(ctx, "unknown exception");
 }
 
-int ptc_set_background(ptc_context* ctx, float r, float g, float b) {
+int ptc_set_background(ptc_context* ctx, float r, float g, float b) try {
     ENTER();
     ctx->bg[0] = r;
     ctx->bg[1] = g;
     ctx->bg[2] = b;
     return PTC_OK;
+} catch (const std::exception& e) {
+    return caught(ctx, e.what());
+} catch (...) {
+    return caught(ctx, "unknown exception");
 }
 
-int ptc_build(ptc_context* ctx) {
+int ptc_build(ptc_context* ctx) try {
     ENTER();
     CHK(hipStreamSynchronize(ctx->stream));
     const hipEvent_t e0 = ctx->ev_t0, e1 = ctx->ev_t1;  // owned by the context: no error path can leak them
@@ -825,15 +868,23 @@ int ptc_build(ptc_context* ctx) {
     ctx->stats.bvh_max_depth = ctx->bvh.max_depth;
     ctx->built = true;
     return PTC_OK;
+} catch (const std::exception& e) {
+    return caught(ctx, e.what());
+} catch (...) {
+    return caught(ctx, "unknown exception");
 }
 
-int ptc_render_range(ptc_context* ctx, int frame_id, uint32_t width, uint32_t height, int32_t spp_begin, int32_t spp_end, int clear) {
+int ptc_render_range(ptc_context* ctx, int frame_id, uint32_t width, uint32_t height, int32_t spp_begin, int32_t spp_end, int clear) try {
     ENTER();
     return renderRange(ctx, frame_id, width, height, spp_begin, spp_end, clear);
+} catch (const std::exception& e) {
+    return caught(ctx, e.what());
+} catch (...) {
+    return caught(ctx, "unknown exception");
 }
 
 int ptc_render_range_static(ptc_context* ctx, int frame_id, uint32_t width, uint32_t height, int32_t spp_begin, int32_t spp_end, int clear,
-                            void* sums_device, size_t sums_bytes) {
+                            void* sums_device, size_t sums_bytes) try {
     ENTER();
     RenderParams rp;
     int rc = makeParams(ctx, frame_id, width, height, rp);
@@ -897,18 +948,26 @@ int ptc_render_range_static(ptc_context* ctx, int frame_id, uint32_t width, uint
     ctx->acc = saved.acc;
     ctx->no_alloc = saved.no_alloc;
     return rc;
+} catch (const std::exception& e) {
+    return caught(ctx, e.what());
+} catch (...) {
+    return caught(ctx, "unknown exception");
 }
 
-int ptc_resolve(ptc_context* ctx, int frame_id, int32_t total_spp) {
+int ptc_resolve(ptc_context* ctx, int frame_id, int32_t total_spp) try {
     ENTER();
     if (!ctx->width) return fail(ctx, PTC_ERR_INVALID, "nothing rendered yet");
     if (!ctx->have_cfg) return fail(ctx, PTC_ERR_INVALID, "ptc_set_config has not been called");
     wf_resolve(ctx->stream, ctx->acc, ctx->result, ctx->width * ctx->height, total_spp, ctx->cfg.gamma, frame_id);
     CHK(hipGetLastError());
     return PTC_OK;
+} catch (const std::exception& e) {
+    return caught(ctx, e.what());
+} catch (...) {
+    return caught(ctx, "unknown exception");
 }
 
-int ptc_render(ptc_context* ctx, int frame_id, uint32_t width, uint32_t height) {
+int ptc_render(ptc_context* ctx, int frame_id, uint32_t width, uint32_t height) try {
     ENTER();
     int rc = renderRange(ctx, frame_id, width, height, 0, ctx->spp, 1);
     if (rc) return rc;
@@ -916,9 +975,13 @@ int ptc_render(ptc_context* ctx, int frame_id, uint32_t width, uint32_t height) 
     if (rc) return rc;
     CHK(hipStreamSynchronize(ctx->stream));
     return PTC_OK;
+} catch (const std::exception& e) {
+    return caught(ctx, e.what());
+} catch (...) {
+    return caught(ctx, "unknown exception");
 }
 
-int ptc_primary_hits(ptc_context* ctx, uint32_t width, uint32_t height, PtcHitRecord* out) {
+int ptc_primary_hits(ptc_context* ctx, uint32_t width, uint32_t height, PtcHitRecord* out) try {
     ENTER();
     if (!out) return fail(ctx, PTC_ERR_INVALID, "null output");
     RenderParams rp;
@@ -947,25 +1010,37 @@ int ptc_primary_hits(ptc_context* ctx, uint32_t width, uint32_t height, PtcHitRe
     CHK(hipStreamSynchronize(ctx->stream));
     CHK(hipGetLastError());
     return PTC_OK;
+} catch (const std::exception& e) {
+    return caught(ctx, e.what());
+} catch (...) {
+    return caught(ctx, "unknown exception");
 }
 
-int ptc_read_result(ptc_context* ctx, float* rgb_out) {
+int ptc_read_result(ptc_context* ctx, float* rgb_out) try {
     ENTER();
     if (!rgb_out || !ctx->width) return fail(ctx, PTC_ERR_INVALID, "nothing to read");
     CHK(hipMemcpyAsync(rgb_out, ctx->result, (size_t)ctx->width * ctx->height * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     CHK(hipStreamSynchronize(ctx->stream));
     return PTC_OK;
+} catch (const std::exception& e) {
+    return caught(ctx, e.what());
+} catch (...) {
+    return caught(ctx, "unknown exception");
 }
 
-int ptc_read_sum(ptc_context* ctx, float* rgb_out) {
+int ptc_read_sum(ptc_context* ctx, float* rgb_out) try {
     ENTER();
     if (!rgb_out || !ctx->width) return fail(ctx, PTC_ERR_INVALID, "nothing to read");
     CHK(hipMemcpyAsync(rgb_out, ctx->acc, (size_t)ctx->width * ctx->height * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     CHK(hipStreamSynchronize(ctx->stream));
     return PTC_OK;
+} catch (const std::exception& e) {
+    return caught(ctx, e.what());
+} catch (...) {
+    return caught(ctx, "unknown exception");
 }
 
-int ptc_bind_sum_buffer(ptc_context* ctx, void* device_ptr, size_t bytes) {
+int ptc_bind_sum_buffer(ptc_context* ctx, void* device_ptr, size_t bytes) try {
     ENTER();
     if (device_ptr && ctx->width && bytes < (size_t)ctx->width * ctx->height * 3 * sizeof(float))
         return fail(ctx, PTC_ERR_INVALID, "sum buffer too small for the current image");
@@ -973,22 +1048,34 @@ int ptc_bind_sum_buffer(ptc_context* ctx, void* device_ptr, size_t bytes) {
     ctx->acc_ext_bytes = bytes;
     if (ctx->width) ctx->acc = device_ptr ? (float*)device_ptr : ctx->acc_own;
     return PTC_OK;
+} catch (const std::exception& e) {
+    return caught(ctx, e.what());
+} catch (...) {
+    return caught(ctx, "unknown exception");
 }
 
-int ptc_set_stream(ptc_context* ctx, void* hip_stream) {
+int ptc_set_stream(ptc_context* ctx, void* hip_stream) try {
     ENTER();
     CHK(hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
     return PTC_OK;
+} catch (const std::exception& e) {
+    return caught(ctx, e.what());
+} catch (...) {
+    return caught(ctx, "unknown exception");
 }
 
-int ptc_synchronize(ptc_context* ctx) {
+int ptc_synchronize(ptc_context* ctx) try {
     ENTER();
     CHK(hipStreamSynchronize(ctx->stream));
     return PTC_OK;
+} catch (const std::exception& e) {
+    return caught(ctx, e.what());
+} catch (...) {
+    return caught(ctx, "unknown exception");
 }
 
-int ptc_probe_segments(ptc_context* ctx, uint32_t n, const PtcSegmentProbe* in, PtcSegmentResult* out) {
+int ptc_probe_segments(ptc_context* ctx, uint32_t n, const PtcSegmentProbe* in, PtcSegmentResult* out) try {
     ENTER();
     if (n == 0) return PTC_OK;
     if (!in || !out) return fail(ctx, PTC_ERR_INVALID, "null probe array");
@@ -1070,9 +1157,13 @@ int ptc_probe_segments(ptc_context* ctx, uint32_t n, const PtcSegmentProbe* in, 
         std::memcpy(&r.depth, &d[k].w, 4);
     }
     return PTC_OK;
+} catch (const std::exception& e) {
+    return caught(ctx, e.what());
+} catch (...) {
+    return caught(ctx, "unknown exception");
 }
 
-int ptc_eval_shading(ptc_context* ctx, int fn, uint32_t n, const float* in16, float* out4) {
+int ptc_eval_shading(ptc_context* ctx, int fn, uint32_t n, const float* in16, float* out4) try {
     ENTER();
     if (n == 0) return PTC_OK;
     if (!in16 || !out4 || fn < 0 || fn > 4) return fail(ctx, PTC_ERR_INVALID, "bad argument");
@@ -1089,9 +1180,13 @@ int ptc_eval_shading(ptc_context* ctx, int fn, uint32_t n, const float* in16, fl
     if (d_out) (void)hipFree(d_out);
     if (e != hipSuccess) return fail(ctx, PTC_ERR_DEVICE, std::string("ptc_eval_shading: ") + hipGetErrorString(e));
     return PTC_OK;
+} catch (const std::exception& e) {
+    return caught(ctx, e.what());
+} catch (...) {
+    return caught(ctx, "unknown exception");
 }
 
-int ptc_set_option(ptc_context* ctx, int option, int64_t value) {
+int ptc_set_option(ptc_context* ctx, int option, int64_t value) try {
     ENTER();
     switch (option) {
         case PTC_OPT_SEMANTICS:
@@ -1131,23 +1226,35 @@ int ptc_set_option(ptc_context* ctx, int option, int64_t value) {
         default: return fail(ctx, PTC_ERR_INVALID, "unknown option");
     }
     return PTC_OK;
+} catch (const std::exception& e) {
+    return caught(ctx, e.what());
+} catch (...) {
+    return caught(ctx, "unknown exception");
 }
 
-int ptc_collapse_wide(const void* binary_nodes, uint32_t n_nodes, void* wide_nodes_out, uint32_t capacity, uint32_t* n_wide_out, uint32_t* depth_out) {
+int ptc_collapse_wide(const void* binary_nodes, uint32_t n_nodes, void* wide_nodes_out, uint32_t capacity, uint32_t* n_wide_out, uint32_t* depth_out) try {
     if (!binary_nodes || !wide_nodes_out || !n_wide_out || !depth_out || n_nodes == 0) return PTC_ERR_INVALID;
     const int rc = bvh_collapse_wide_host((const BvhNode*)binary_nodes, n_nodes, (WideNode*)wide_nodes_out, capacity, n_wide_out, depth_out);
     return rc == 0 ? PTC_OK : rc == 1 ? PTC_ERR_UNSUPPORTED : PTC_ERR_INVALID;  // 2 = capacity, 3 = malformed nodes
+} catch (const std::exception& e) {
+    return caught(nullptr, e.what());
+} catch (...) {
+    return caught(nullptr, "unknown exception");
 }
 
-int ptc_debug_counters(ptc_context* ctx, uint64_t* out, uint32_t n) {
+int ptc_debug_counters(ptc_context* ctx, uint64_t* out, uint32_t n) try {
     ENTER();
     if (!out || n > N_COUNTERS) return fail(ctx, PTC_ERR_INVALID, "bad argument");
     CHK(hipStreamSynchronize(ctx->stream));
     CHK(hipMemcpy(out, ctx->counters, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return PTC_OK;
+} catch (const std::exception& e) {
+    return caught(ctx, e.what());
+} catch (...) {
+    return caught(ctx, "unknown exception");
 }
 
-int ptc_get_stats(ptc_context* ctx, PtcStats* out) {
+int ptc_get_stats(ptc_context* ctx, PtcStats* out) try {
     ENTER();
     if (!out) return fail(ctx, PTC_ERR_INVALID, "null output");
     CHK(hipStreamSynchronize(ctx->stream));
@@ -1161,9 +1268,13 @@ int ptc_get_stats(ptc_context* ctx, PtcStats* out) {
     ctx->stats.shadow_rays = h[4];
     *out = ctx->stats;
     return PTC_OK;
+} catch (const std::exception& e) {
+    return caught(ctx, e.what());
+} catch (...) {
+    return caught(ctx, "unknown exception");
 }
 
-int ptc_reset_stats(ptc_context* ctx) {
+int ptc_reset_stats(ptc_context* ctx) try {
     ENTER();
     CHK(hipStreamSynchronize(ctx->stream));
     collectSpans(ctx);
@@ -1178,6 +1289,10 @@ int ptc_reset_stats(ptc_context* ctx) {
     ctx->stats.bvh_nodes = nodes;
     ctx->stats.bvh_max_depth = depth;
     return PTC_OK;
+} catch (const std::exception& e) {
+    return caught(ctx, e.what());
+} catch (...) {
+    return caught(ctx, "unknown exception");
 }
 
 }  // extern "C"
