@@ -88,9 +88,14 @@ void pth_result_to_rgba8(const float* result, uint32_t width, uint32_t height, u
 }
 
 int pth_write_png(const char* filename, const unsigned char* rgba, uint32_t width, uint32_t height) {
-    std::string err;
-    if (!png_write_rgba8(filename, rgba, width, height, &err)) { g_error = err; return -1; }
-    return 0;
+    try {
+        std::string err;
+        if (!png_write_rgba8(filename, rgba, width, height, &err)) { g_error = err; return -1; }
+        return 0;
+    } catch (const std::exception& e) {  // the encoder's buffers
+        g_error = e.what();
+        return -1;
+    }
 }
 
 }  // extern "C"
