@@ -267,10 +267,13 @@ __global__ __launch_bounds__(BLOCK) void k_pixel_seeds(RenderParams rp, uint32_t
     pixseed[pix] = pixel_of(rp, pix, x, y) ? tea16((x * rp.height + y) * rp.frame_id, 0u) : 0u;
 }
 
-__global__ __launch_bounds__(GEN_BLOCK) void k_generate(RenderParams rp, PathState ps, uint32_t npix_pad, uint32_t n_paths, uint32_t sample_begin,
+#ifndef CAM_BLOCK
+#define CAM_BLOCK 256   /* no barrier and no atomic in this kernel: small blocks, so that a CU never waits for sixteen wave slots at once */
+#endif
+__global__ __launch_bounds__(CAM_BLOCK) void k_generate(RenderParams rp, PathState ps, uint32_t npix_pad, uint32_t n_paths, uint32_t sample_begin,
                                                     const float* __restrict__ acc, uint32_t* __restrict__ segctr, const uint32_t* __restrict__ pixseed,
                                                     int seed_L_from_acc) {
-    const uint32_t p = blockIdx.x * GEN_BLOCK + threadIdx.x;
+    const uint32_t p = blockIdx.x * CAM_BLOCK + threadIdx.x;
     if (p >= n_paths) return;  // whole waves: the number of paths is a multiple of 64
     uint32_t x = 0, y = 0, pix = 0, j = 0;
     path_split(rp, p, pix, j);
@@ -1627,7 +1630,7 @@ static inline uint32_t blocks_for(uint64_t n, uint32_t block = BLOCK) { return (
 void wf_generate(hipStream_t s, const RenderParams& rp, const PathState& ps, uint32_t npix_pad, uint32_t n_paths, uint32_t sample_begin,
                  const float* acc, uint32_t* segctr, uint32_t* pixseed, int seed_L_from_acc) {
     hipLaunchKernelGGL(k_pixel_seeds, dim3(blocks_for(npix_pad)), dim3(BLOCK), 0, s, rp, npix_pad, pixseed);
-    hipLaunchKernelGGL(k_generate, dim3(blocks_for(n_paths, GEN_BLOCK)), dim3(GEN_BLOCK), 0, s, rp, ps, npix_pad, n_paths, sample_begin, acc, segctr, pixseed,
+    hipLaunchKernelGGL(k_generate, dim3(blocks_for(n_paths, CAM_BLOCK)), dim3(CAM_BLOCK), 0, s, rp, ps, npix_pad, n_paths, sample_begin, acc, segctr, pixseed,
                        seed_L_from_acc);
 }
 
