@@ -191,47 +191,70 @@ __device__ __forceinline__ void queue_reserve_streams(const bool keep[N], uint32
 
 // The same for four streams at once, with one round of barriers: streams 0 and 1 go to
 // `c01` (all of stream 0 of the block, then all of stream 1), stream 2 to `c2`, stream 3
-// to `c3`.  at[k] receives the position for the streams this thread appends to.
-__device__ __forceinline__ void queue_reserve4(bool k0, bool k1, bool k2, bool k3, uint32_t* __restrict__ c01, uint32_t* __restrict__ c2, uint32_t* __restrict__ c3,
-                                               uint32_t at[4]) {
-    __shared__ uint32_t s_cnt[16][4];
-    __shared__ uint32_t s_base[4];
+// to `c3`.  In two halves, so that the caller can put work that does not depend on the positions
+// between them: the block's three atomics are in flight meanwhile (a reservation costs a block the round
+// trip to the counter word, one to two microseconds with every block of the grid asking the same word).
+// Once per kernel (the halves share LDS words that are not guarded against a second call).
+struct Reserve4 {
+    unsigned long long m0, m1, m2, m3;  // who appends to which stream (wave-uniform)
+    uint32_t base, first;               // threads 0..2: the block's first position on their counter; thread 0: entries of stream 0
+};
+struct Reserve4Lds {
+    uint32_t cnt[16][4];
+    uint32_t base[4];
+};
+
+__device__ __forceinline__ void reserve4_begin(Reserve4& r, Reserve4Lds& L, bool k0, bool k1, bool k2, bool k3, uint32_t* __restrict__ c01, uint32_t* __restrict__ c2,
+                                               uint32_t* __restrict__ c3) {
     const uint32_t lane = __lane_id();
     const uint32_t wave = threadIdx.x >> 6, nwaves = (blockDim.x + 63u) >> 6;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1), m2 = __ballot(k2), m3 = __ballot(k3);
-    __syncthreads();  // the previous call's readers are done
+    r.m0 = __ballot(k0);
+    r.m1 = __ballot(k1);
+    r.m2 = __ballot(k2);
+    r.m3 = __ballot(k3);
+    r.base = r.first = 0u;
     if (lane == 0) {
-        s_cnt[wave][0] = (uint32_t)__popcll(m0);
-        s_cnt[wave][1] = (uint32_t)__popcll(m1);
-        s_cnt[wave][2] = (uint32_t)__popcll(m2);
-        s_cnt[wave][3] = (uint32_t)__popcll(m3);
+        L.cnt[wave][0] = (uint32_t)__popcll(r.m0);
+        L.cnt[wave][1] = (uint32_t)__popcll(r.m1);
+        L.cnt[wave][2] = (uint32_t)__popcll(r.m2);
+        L.cnt[wave][3] = (uint32_t)__popcll(r.m3);
     }
     __syncthreads();
     if (threadIdx.x < 3u) {
         uint32_t t0 = 0, t1 = 0;
         const uint32_t k = threadIdx.x == 0u ? 0u : threadIdx.x + 1u;
         for (uint32_t w = 0; w < nwaves; ++w) {
-            t0 += s_cnt[w][k];
-            if (threadIdx.x == 0u) t1 += s_cnt[w][1];
+            t0 += L.cnt[w][k];
+            if (threadIdx.x == 0u) t1 += L.cnt[w][1];
         }
         uint32_t* c = threadIdx.x == 0u ? c01 : threadIdx.x == 1u ? c2 : c3;
-        const uint32_t b = (t0 + t1) ? atomicAdd(c, t0 + t1) : 0u;
-        s_base[k] = b;
-        if (threadIdx.x == 0u) s_base[1] = b + t0;
+        r.base = (t0 + t1) ? atomicAdd(c, t0 + t1) : 0u;
+        r.first = t0;
+    }
+}
+
+// at[k] receives the position for the streams this thread appends to.
+__device__ __forceinline__ void reserve4_end(const Reserve4& r, Reserve4Lds& L, uint32_t at[4]) {
+    const uint32_t lane = __lane_id();
+    const uint32_t wave = threadIdx.x >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    if (threadIdx.x < 3u) {
+        const uint32_t k = threadIdx.x == 0u ? 0u : threadIdx.x + 1u;
+        L.base[k] = r.base;
+        if (threadIdx.x == 0u) L.base[1] = r.base + r.first;
     }
     __syncthreads();
-    uint32_t b0 = s_base[0], b1 = s_base[1], b2 = s_base[2], b3 = s_base[3];
+    uint32_t b0 = L.base[0], b1 = L.base[1], b2 = L.base[2], b3 = L.base[3];
     for (uint32_t w = 0; w < wave; ++w) {
-        b0 += s_cnt[w][0];
-        b1 += s_cnt[w][1];
-        b2 += s_cnt[w][2];
-        b3 += s_cnt[w][3];
+        b0 += L.cnt[w][0];
+        b1 += L.cnt[w][1];
+        b2 += L.cnt[w][2];
+        b3 += L.cnt[w][3];
     }
-    at[0] = b0 + (uint32_t)__popcll(m0 & lt);
-    at[1] = b1 + (uint32_t)__popcll(m1 & lt);
-    at[2] = b2 + (uint32_t)__popcll(m2 & lt);
-    at[3] = b3 + (uint32_t)__popcll(m3 & lt);
+    at[0] = b0 + (uint32_t)__popcll(r.m0 & lt);
+    at[1] = b1 + (uint32_t)__popcll(r.m1 & lt);
+    at[2] = b2 + (uint32_t)__popcll(r.m2 & lt);
+    at[3] = b3 + (uint32_t)__popcll(r.m3 & lt);
 }
 
 __device__ __forceinline__ uint32_t segment_seed(const RenderParams& rp, uint32_t key0, uint32_t sample, uint32_t bounce, uint32_t* segctr, uint32_t pix) {
@@ -1459,23 +1482,29 @@ __global__ __launch_bounds__(SURF_BLOCK_MANY, SURF_WAVES) void k_surface(RenderP
         // PinholeCamera.cu:66 plus the segment cap and the zero-throughput cull
         alive = !sg.done && sg.depth != rp.max_depth_eff && bounce < rp.bounce_cap;
         if (alive && rp.cull_zero && sg.thr.x == 0.f && sg.thr.y == 0.f && sg.thr.z == 0.f) alive = false;
-        if (alive) {
-            uint32_t pix, x, y;
-            uint32_t sample;
-            path_split(rp, p, pix, sample);
-            sample += sample_begin;
-            pixel_of(rp, pix, x, y);
-            const uint32_t key0 = (x * rp.height + y) * rp.frame_id;
-            const uint32_t seed = segment_seed(rp, key0, sample, bounce, segctr, pix);
-            n_o = make_float4(sg.o.x, sg.o.y, sg.o.z, u2f(seed));
-            n_d = make_float4(sg.d.x, sg.d.y, sg.d.z, u2f(sg.depth));
-            n_t = make_float4(sg.thr.x, sg.thr.y, sg.thr.z, u2f(bounce));
-        }
+    }
+    // the queue positions of this block are asked for now and used after the survivor's next seed (tea<16>, the
+    // longest dependent chain of the kernel) has been computed.  (Asking for the shadow rays' positions earlier
+    // still, before the closest-hit program, costs a barrier in the middle of the kernel: +17 ms per frame.)
+    __shared__ Reserve4Lds rs_lds;
+    Reserve4 rs;
+    if (few) reserve4_begin(rs, rs_lds, f_need[0], f_need[1], gather, alive, shadow_count, gather_count, next_count);
+    if (alive) {
+        uint32_t pix, x, y;
+        uint32_t sample;
+        path_split(rp, p, pix, sample);
+        sample += sample_begin;
+        pixel_of(rp, pix, x, y);
+        const uint32_t key0 = (x * rp.height + y) * rp.frame_id;
+        const uint32_t seed = segment_seed(rp, key0, sample, bounce, segctr, pix);
+        n_o = make_float4(sg.o.x, sg.o.y, sg.o.z, u2f(seed));
+        n_d = make_float4(sg.d.x, sg.d.y, sg.d.z, u2f(sg.depth));
+        n_t = make_float4(sg.thr.x, sg.thr.y, sg.thr.z, u2f(bounce));
     }
     uint32_t next_at = 0;  // the survivor's position in the next bounce's (packed) path state
     if (few) {
         uint32_t pos[4];
-        queue_reserve4(f_need[0], f_need[1], gather, alive, shadow_count, gather_count, next_count, pos);
+        reserve4_end(rs, rs_lds, pos);
 #pragma unroll
         for (uint32_t q = 0; q < 2u; ++q)
             if (f_need[q]) {
