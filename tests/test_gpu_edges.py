@@ -163,6 +163,9 @@ def test_error_behaviour():
         assert lib.ptc_build(ctx) == 0
         assert lib.ptc_render(ctx, 1, 0, 16) == _ffi.ERR_INVALID             # empty image
         assert lib.ptc_render_range(ctx, 1, 16, 16, 3, 2, 1) == _ffi.ERR_INVALID  # reversed range
+        assert lib.ptc_render_range(ctx, 1, 16, 16, 0, 0, 1) == 0                 # an empty range is no error
+        assert lib.ptc_render(ctx, 1, 70000, 70000) == _ffi.ERR_INVALID      # more pixels than 32-bit pixel numbers
+        assert b"too large" in lib.ptc_last_error(ctx)
         assert lib.ptc_render_range(ctx, 1, 16, 16, 2, 4, 1) == _ffi.ERR_INVALID  # reference seeding cannot start at sample 2
         assert lib.ptc_set_option(ctx, 12345, 1) == _ffi.ERR_INVALID
         assert lib.ptc_set_option(ctx, _ffi.OPT_BOUNCE_CAP, 0) == _ffi.ERR_INVALID
