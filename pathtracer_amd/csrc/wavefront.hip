@@ -373,12 +373,54 @@ __device__ __forceinline__ uint32_t wave_fetch(WaveWork& w, bool idle, uint32_t*
     return idx;
 }
 
+// ---- small scenes: hierarchy and primitives in LDS ---------------------------------------------
+// A scene of a few dozen primitives (the Cornell boxes, scene 2) is a couple of kilobytes: every block copies the
+// binary nodes, the triangle and sphere records and their primitive numbers into LDS once and traverses that copy.
+// The node and primitive fetches of a step then are LDS reads (tens of cycles, no work for the vector memory
+// pipeline) instead of L1 hits (hundreds of cycles through the texture addresser, which these kernels keep busy);
+// the arithmetic and its results are the same.  LDS_SCENE_BYTES is what the stacks of six resident blocks per
+// CU leave free (6 x (24 KB + 2.5 KB) = 159 KB of 160).  Only the refilling kernels do this: their blocks live
+// for the whole launch, whereas a block of the one-ray-per-thread kernels would copy the scene for 256 rays
+// (measured: scene 2 sphere.test shadow rays 8.2 -> 9.1 ms with the copy in k_shadow_static, 5.8 ms in k_shadow).
+#define LDS_SCENE_BYTES 2560u
+static __host__ __device__ inline uint32_t lds_scene_bytes(const DevScene& sc) {
+    return sc.n_nodes * 64u + sc.n_tris * 48u + sc.n_spheres * 128u + (((sc.n_tris + sc.n_spheres) * 4u + 15u) & ~15u);
+}
+// View of `sc` whose traversal arrays are the block's LDS copy (LDS = false: `sc` itself).  All threads of the
+// block must call it; it ends with a barrier.
+template <bool LDS>
+__device__ __forceinline__ DevScene scene_in_lds(const DevScene& sc, uint4* __restrict__ lds) {
+    DevScene v = sc;
+    if (LDS) {
+        const uint32_t o_tri = sc.n_nodes * 4u, o_sph = o_tri + sc.n_tris * 3u, o_prim = o_sph + sc.n_spheres * 8u;  // in 16-byte units
+        const uint4* g_nodes = reinterpret_cast<const uint4*>(sc.nodes);
+        const uint4* g_tri = reinterpret_cast<const uint4*>(sc.tri_q);
+        const uint4* g_sph = reinterpret_cast<const uint4*>(sc.spheres);
+        for (uint32_t k = threadIdx.x; k < o_tri; k += blockDim.x) lds[k] = g_nodes[k];
+        for (uint32_t k = threadIdx.x; k < sc.n_tris * 3u; k += blockDim.x) lds[o_tri + k] = g_tri[k];
+        for (uint32_t k = threadIdx.x; k < sc.n_spheres * 8u; k += blockDim.x) lds[o_sph + k] = g_sph[k];
+        int32_t* prim = reinterpret_cast<int32_t*>(lds + o_prim);
+        for (uint32_t k = threadIdx.x; k < sc.n_tris; k += blockDim.x) prim[k] = sc.tri_prim[k];
+        for (uint32_t k = threadIdx.x; k < sc.n_spheres; k += blockDim.x) prim[sc.n_tris + k] = sc.sph_prim[k];
+        v.nodes = reinterpret_cast<const BvhNode*>(lds);
+        v.tri_q = reinterpret_cast<const float4*>(lds + o_tri);
+        v.spheres = reinterpret_cast<const DevSphere*>(lds + o_sph);
+        v.tri_prim = prim;
+        v.sph_prim = prim + sc.n_tris;
+        __syncthreads();
+    }
+    return v;
+}
+#define LDS_SCENE_WORDS(LDS) ((LDS) ? LDS_SCENE_BYTES / 16u : 1u)
+
 // Closest hit of the live paths, i.e. of entries [0, count) of the path state: hit_t / hit_ref
 // at the same position.
-template <bool COUNT>
-__global__ __launch_bounds__(BLOCK) void k_extend(RenderParams rp, DevScene sc, PathState ps, uint32_t count,
+template <bool COUNT, bool LDS = false>
+__global__ __launch_bounds__(BLOCK) void k_extend(RenderParams rp, DevScene sc_global, PathState ps, uint32_t count,
                                                   uint32_t* __restrict__ work_counter, uint32_t wave_chunk, unsigned long long* __restrict__ trav_counters) {
     __shared__ uint32_t stack[TRAV_LDS_STACK * BLOCK];
+    __shared__ uint4 scene_copy[LDS_SCENE_WORDS(LDS)];
+    const DevScene sc = scene_in_lds<LDS>(sc_global, scene_copy);
     uint32_t* my_stack = stack + threadIdx.x;
     uint32_t spill[TRAV_SPILL_STACK];
     TravRay r;
@@ -925,11 +967,13 @@ __device__ __forceinline__ vec3 light_sample(const RenderParams& rp, const DevSc
 
 // ------------------------------------------------------------------ shadow --
 // Any-hit traversal of the queued shadow rays, same work distribution as k_extend.
-template <bool COUNT>
-__global__ __launch_bounds__(BLOCK) void k_shadow(RenderParams rp, DevScene sc, PathState ps, const uint32_t* __restrict__ count_ptr,
+template <bool COUNT, bool LDS = false>
+__global__ __launch_bounds__(BLOCK) void k_shadow(RenderParams rp, DevScene sc_global, PathState ps, const uint32_t* __restrict__ count_ptr,
                                                   uint32_t* __restrict__ work_counter, uint32_t wave_chunk, unsigned long long* __restrict__ trav_counters,
                                                   unsigned long long* __restrict__ shadow_total) {
     __shared__ uint32_t stack[TRAV_LDS_STACK * BLOCK];
+    __shared__ uint4 scene_copy[LDS_SCENE_WORDS(LDS)];
+    const DevScene sc = scene_in_lds<LDS>(sc_global, scene_copy);
     const uint32_t count = *count_ptr;
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(shadow_total, (unsigned long long)count);
     const size_t plane = (size_t)rp.samples_per_path * ps.capacity;
@@ -1698,11 +1742,25 @@ static uint32_t deferred_resident_waves() {
 // enough for refilling waves to pay, for the closest-hit rays first (Cornell box + GGX sphere, 8 nodes: extension
 // 184 ms refilling / 192 ms static, shadow 62 / 53 ms; cornellRR, 13 nodes: 53 / 60 and 21 / 24 ms); real meshes
 // take the deferred tests over the four-wide nodes.
+// A scene whose traversal arrays fit the LDS copy of the refilling kernels (Cornell boxes, scene 2) takes those for
+// its shadow rays whatever the node count, and for its extension rays above 6 nodes (Cornell box + GGX sphere:
+// 433 -> 390 ms per frame, extension 174 -> 106 ms, shadow 51 -> 39 ms; cornellRR 117.5 -> 97 ms; scene 2
+// sphere.test 5.7 -> 4.9 ms, its camera rays stay with the static kernel: 0.2 against 0.7 ms).
 #define STATIC_EXT_NODES 6u
 #define STATIC_SHADOW_NODES 8u
 #define TINY_BVH_NODES 64u
+// The traversal arrays of the scene fit the LDS copy of the small-scene kernels (and there is a hierarchy to copy).
+#ifndef LDS_SCENE_OFF
+#define LDS_SCENE_OFF 0
+#endif
+static bool scene_fits_lds(const DevScene& sc) {
+    return !LDS_SCENE_OFF && sc.n_nodes != 0u && sc.nodes != nullptr && lds_scene_bytes(sc) <= LDS_SCENE_BYTES;
+}
+
 static uint32_t auto_mode(const DevScene& sc, bool shadow) {
-    return sc.n_nodes <= (shadow ? STATIC_SHADOW_NODES : STATIC_EXT_NODES) ? 0u : sc.n_nodes <= TINY_BVH_NODES ? 1u : 6u;
+    if (sc.n_nodes > TINY_BVH_NODES) return 6u;
+    if (scene_fits_lds(sc)) return (!shadow && sc.n_nodes <= STATIC_EXT_NODES) ? 0u : 1u;
+    return sc.n_nodes <= (shadow ? STATIC_SHADOW_NODES : STATIC_EXT_NODES) ? 0u : 1u;
 }
 
 // The item word of the deferred-test kernels holds 25 bits of primitive slot.
@@ -1737,6 +1795,8 @@ void wf_extend(hipStream_t s, const RenderParams& rp, const DevScene& sc, const 
         hipLaunchKernelGGL(k_extend_static<false>, dim3(blocks_for(count)), dim3(BLOCK), 0, s, rp, sc, ps, count, trav_counters);
     else if (count_trav)
         hipLaunchKernelGGL(k_extend<true>, dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, count, work_counter, wave_chunk, trav_counters);
+    else if (scene_fits_lds(sc))
+        hipLaunchKernelGGL((k_extend<false, true>), dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, count, work_counter, wave_chunk, trav_counters);
     else
         hipLaunchKernelGGL(k_extend<false>, dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, count, work_counter, wave_chunk, trav_counters);
 }
@@ -1767,6 +1827,8 @@ void wf_shadow(hipStream_t s, const RenderParams& rp, const DevScene& sc, const 
         hipLaunchKernelGGL(k_shadow_static<false>, dim3(blocks_for(max_rays)), dim3(BLOCK), 0, s, rp, sc, ps, count_ptr, trav_counters, shadow_total);
     else if (count_trav)
         hipLaunchKernelGGL(k_shadow<true>, dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, count_ptr, work_counter, wave_chunk, trav_counters, shadow_total);
+    else if (scene_fits_lds(sc))
+        hipLaunchKernelGGL((k_shadow<false, true>), dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, count_ptr, work_counter, wave_chunk, trav_counters, shadow_total);
     else
         hipLaunchKernelGGL(k_shadow<false>, dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, count_ptr, work_counter, wave_chunk, trav_counters, shadow_total);
 }
