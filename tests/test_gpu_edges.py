@@ -309,6 +309,30 @@ def test_random_soups_against_brute_force(case, builder):
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), hex(tune)
 
 
+@pytest.mark.parametrize("n_tris,n_spheres", [(1, 0), (0, 1), (7, 1), (24, 1), (30, 0), (12, 6), (3, 9), (36, 2), (60, 0)])
+def test_small_scenes_against_brute_force(n_tris, n_spheres):
+    """Scenes of a few dozen primitives: the refilling kernels traverse a copy of the hierarchy and the primitives
+    in LDS when it fits 2.5 KB (the first seven cases do, the last two do not) and the arrays in memory otherwise;
+    both, the one-ray-per-thread kernels and the automatic choice agree bit for bit with brute force, for both ray
+    classes (closest-hit camera and reflection rays, any-hit shadow rays to the point light)."""
+    scene = soup(n_tris=n_tris, n_spheres=n_spheres, seed=100 + n_tris + n_spheres)
+    b = Renderer(scene, options={_ffi.OPT_BRUTE_FORCE: 1})
+    want_hits = b.primary_hits()
+    b.run()
+    want = b.sums()
+    b.close()
+    for builder in (0, 3):
+        for tune in (0x1118, 0x1104, 0x2218, 0x0018, 0x5518):
+            r = Renderer(scene, options={_ffi.OPT_BVH_BUILDER: builder, _ffi.OPT_TUNE_TRAVERSAL: tune})
+            hits = r.primary_hits()
+            r.run()
+            got = r.sums()
+            r.close()
+            for f in ("prim", "t", "u", "v"):
+                assert np.array_equal(hits[f].view(np.uint32), want_hits[f].view(np.uint32)), (builder, hex(tune), f)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (builder, hex(tune))
+
+
 @pytest.mark.parametrize("builder", [0, 1, 2, 3])
 def test_many_coincident_primitives(builder):
     """600 exact copies of one triangle inside a soup (an instanced mesh exported twice, stacked decals ...): the

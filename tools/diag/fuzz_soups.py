@@ -12,7 +12,7 @@ n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 rng = np.random.default_rng(1234)
 bad = 0
 for k in range(n_seeds):
-    n_tris = int(rng.choice([1, 2, 3, 4, 5, 7, 9, 16, 33, 100, 300, 1025, 1500, 5000, 20000]))
+    n_tris = int(rng.choice([1, 2, 3, 4, 5, 7, 9, 16, 24, 33, 100, 300, 1025, 1500, 5000, 20000]))
     n_sph = int(rng.choice([0, 0, 1, 3, 9, 40, 200]))
     degenerate = bool(rng.integers(0, 2)) and n_sph == 0
     scene = soup(n_tris=n_tris, n_spheres=n_sph, seed=1000 + k, degenerate=degenerate)
@@ -22,7 +22,7 @@ for k in range(n_seeds):
     want = b.sums()
     b.close()
     for builder in (0, 1, 2, 3):
-        for tune in (0x0020, 0x4420, 0x6620):
+        for tune in (0x0020, 0x1120, 0x4420, 0x6620, 0x5518):
             r = Renderer(scene, options={_ffi.OPT_BVH_BUILDER: builder, _ffi.OPT_TUNE_TRAVERSAL: tune})
             hits = r.primary_hits()
             r.run()
