@@ -426,16 +426,16 @@ __device__ __forceinline__ uint32_t trav_node(const DevScene& sc, const TravRay&
 }
 
 // One single step (either one internal node or one leaf): the "if-if" schedule.
-template <bool ANY, bool COUNT>
+template <bool ANY, bool COUNT, int LDS_N = TRAV_LDS_STACK>
 __device__ __forceinline__ bool trav_step(const DevScene& sc, const TravRay& r, uint32_t* lds_stack, uint32_t* spill, int& sp, uint32_t& cur,
                                           ClosestHit& best, TravCounters& cnt, bool& occluded);
 
 // One round; returns true when the ray is finished (for ANY also when occluded,
 // reported through `occluded`).
-template <bool ANY, bool COUNT>
+template <bool ANY, bool COUNT, int LDS_N = TRAV_LDS_STACK>
 __device__ __forceinline__ bool trav_round(const DevScene& sc, const TravRay& r, uint32_t* lds_stack, uint32_t* spill, int& sp, uint32_t& cur,
                                            ClosestHit& best, TravCounters& cnt, bool& occluded) {
-    while (REF_KIND(cur) == REF_INTERNAL) cur = trav_node<COUNT>(sc, r, cur, ANY ? r.tmax : best.t, lds_stack, spill, sp, cnt);
+    while (REF_KIND(cur) == REF_INTERNAL) cur = trav_node<COUNT, LDS_N>(sc, r, cur, ANY ? r.tmax : best.t, lds_stack, spill, sp, cnt);
     const uint32_t kind = REF_KIND(cur);
     if (kind == REF_TRI) {
         const uint32_t first = REF_FIRST(cur), count = REF_COUNT(cur);
@@ -450,7 +450,7 @@ __device__ __forceinline__ bool trav_round(const DevScene& sc, const TravRay& r,
                 accept_tri(sc, first + k, r.o, r.d, r.tmin, r.tmax, best);
             }
         }
-        cur = trav_pop(lds_stack, spill, sp);
+        cur = trav_pop<LDS_N>(lds_stack, spill, sp);
     } else if (kind == REF_SPHERE) {
         const uint32_t first = REF_FIRST(cur), count = REF_COUNT(cur);
         for (uint32_t k = 0; k < count; ++k) {
@@ -464,19 +464,19 @@ __device__ __forceinline__ bool trav_round(const DevScene& sc, const TravRay& r,
                 accept_sphere(sc, first + k, r.o, r.d, r.tmin, r.tmax, best);
             }
         }
-        cur = trav_pop(lds_stack, spill, sp);
+        cur = trav_pop<LDS_N>(lds_stack, spill, sp);
     }
     return cur == REF_DONE;
 }
 
-template <bool ANY, bool COUNT>
+template <bool ANY, bool COUNT, int LDS_N>
 __device__ __forceinline__ bool trav_step(const DevScene& sc, const TravRay& r, uint32_t* lds_stack, uint32_t* spill, int& sp, uint32_t& cur,
                                           ClosestHit& best, TravCounters& cnt, bool& occluded) {
     if (REF_KIND(cur) == REF_INTERNAL) {
-        cur = trav_node<COUNT>(sc, r, cur, ANY ? r.tmax : best.t, lds_stack, spill, sp, cnt);
+        cur = trav_node<COUNT, LDS_N>(sc, r, cur, ANY ? r.tmax : best.t, lds_stack, spill, sp, cnt);
         return cur == REF_DONE;
     }
-    return trav_round<ANY, COUNT>(sc, r, lds_stack, spill, sp, cur, best, cnt, occluded);
+    return trav_round<ANY, COUNT, LDS_N>(sc, r, lds_stack, spill, sp, cur, best, cnt, occluded);
 }
 
 // The same traversal as one tight loop for a thread that owns a single ray.

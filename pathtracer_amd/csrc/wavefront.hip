@@ -374,15 +374,19 @@ __device__ __forceinline__ uint32_t wave_fetch(WaveWork& w, bool idle, uint32_t*
 }
 
 // ---- small scenes: hierarchy and primitives in LDS ---------------------------------------------
-// A scene of a few dozen primitives (the Cornell boxes, scene 2) is a couple of kilobytes: every block copies the
-// binary nodes, the triangle and sphere records and their primitive numbers into LDS once and traverses that copy.
+// A scene of a few dozen primitives (the Cornell boxes, scene 2, most of scene 1) is a few kilobytes: every block copies
+// the binary nodes, the triangle and sphere records and their primitive numbers into LDS once and traverses that copy.
 // The node and primitive fetches of a step then are LDS reads (tens of cycles, no work for the vector memory
 // pipeline) instead of L1 hits (hundreds of cycles through the texture addresser, which these kernels keep busy);
-// the arithmetic and its results are the same.  LDS_SCENE_BYTES is what the stacks of six resident blocks per
-// CU leave free (6 x (24 KB + 2.5 KB) = 159 KB of 160).  Only the refilling kernels do this: their blocks live
-// for the whole launch, whereas a block of the one-ray-per-thread kernels would copy the scene for 256 rays
-// (measured: scene 2 sphere.test shadow rays 8.2 -> 9.1 ms with the copy in k_shadow_static, 5.8 ms in k_shadow).
-#define LDS_SCENE_BYTES 2560u
+// the arithmetic and its results are the same.  Such a hierarchy is shallow (at most 64 nodes are allowed), so these
+// kernels keep 8 stack entries per ray in LDS instead of 24 (deeper ones go to scratch as always) and the copy takes the
+// 16 KB that frees: the LDS per block, and with it the six resident blocks per CU, stay as they are.  Only the
+// refilling kernels do this: their blocks live for the whole launch, whereas a block of the one-ray-per-thread
+// kernels would copy the scene for 256 rays (measured: scene 2 sphere.test shadow rays 8.2 -> 9.1 ms with the copy in
+// k_shadow_static, 5.8 ms in k_shadow).
+#define LDS_SCENE_BYTES 16384u
+#define LDS_SCENE_STACK 8
+#define LDS_SCENE_NODES 64u
 static __host__ __device__ inline uint32_t lds_scene_bytes(const DevScene& sc) {
     return sc.n_nodes * 64u + sc.n_tris * 48u + sc.n_spheres * 128u + (((sc.n_tris + sc.n_spheres) * 4u + 15u) & ~15u);
 }
@@ -418,7 +422,8 @@ __device__ __forceinline__ DevScene scene_in_lds(const DevScene& sc, uint4* __re
 template <bool COUNT, bool LDS = false>
 __global__ __launch_bounds__(BLOCK) void k_extend(RenderParams rp, DevScene sc_global, PathState ps, uint32_t count,
                                                   uint32_t* __restrict__ work_counter, uint32_t wave_chunk, unsigned long long* __restrict__ trav_counters) {
-    __shared__ uint32_t stack[TRAV_LDS_STACK * BLOCK];
+    constexpr int NS = LDS ? LDS_SCENE_STACK : TRAV_LDS_STACK;
+    __shared__ uint32_t stack[NS * BLOCK];
     __shared__ uint4 scene_copy[LDS_SCENE_WORDS(LDS)];
     const DevScene sc = scene_in_lds<LDS>(sc_global, scene_copy);
     uint32_t* my_stack = stack + threadIdx.x;
@@ -451,8 +456,8 @@ __global__ __launch_bounds__(BLOCK) void k_extend(RenderParams rp, DevScene sc_g
         }
         if (active) {
             bool occluded = false;
-            const bool fin = rp.tune_mode == 2 ? trav_step<false, COUNT>(sc, r, my_stack, spill, sp, cur, best, cnt, occluded)
-                                               : trav_round<false, COUNT>(sc, r, my_stack, spill, sp, cur, best, cnt, occluded);
+            const bool fin = rp.tune_mode == 2 ? trav_step<false, COUNT, NS>(sc, r, my_stack, spill, sp, cur, best, cnt, occluded)
+                                               : trav_round<false, COUNT, NS>(sc, r, my_stack, spill, sp, cur, best, cnt, occluded);
             if (fin) {
                 ps.hit_t[p] = best.t;
                 ps.hit_ref[p] = best.ref;
@@ -971,7 +976,8 @@ template <bool COUNT, bool LDS = false>
 __global__ __launch_bounds__(BLOCK) void k_shadow(RenderParams rp, DevScene sc_global, PathState ps, const uint32_t* __restrict__ count_ptr,
                                                   uint32_t* __restrict__ work_counter, uint32_t wave_chunk, unsigned long long* __restrict__ trav_counters,
                                                   unsigned long long* __restrict__ shadow_total) {
-    __shared__ uint32_t stack[TRAV_LDS_STACK * BLOCK];
+    constexpr int NS = LDS ? LDS_SCENE_STACK : TRAV_LDS_STACK;
+    __shared__ uint32_t stack[NS * BLOCK];
     __shared__ uint4 scene_copy[LDS_SCENE_WORDS(LDS)];
     const DevScene sc = scene_in_lds<LDS>(sc_global, scene_copy);
     const uint32_t count = *count_ptr;
@@ -1002,8 +1008,8 @@ __global__ __launch_bounds__(BLOCK) void k_shadow(RenderParams rp, DevScene sc_g
         }
         if (active) {
             bool occluded = false;
-            const bool fin = rp.tune_shadow == 2 ? trav_step<true, COUNT>(sc, r, my_stack, spill, sp, cur, best, cnt, occluded)
-                                                 : trav_round<true, COUNT>(sc, r, my_stack, spill, sp, cur, best, cnt, occluded);
+            const bool fin = rp.tune_shadow == 2 ? trav_step<true, COUNT, NS>(sc, r, my_stack, spill, sp, cur, best, cnt, occluded)
+                                                 : trav_round<true, COUNT, NS>(sc, r, my_stack, spill, sp, cur, best, cnt, occluded);
             if (fin) {
                 if (occluded) {
                     ps.contrib[slot] = 0.f;
@@ -1754,7 +1760,7 @@ static uint32_t deferred_resident_waves() {
 #define LDS_SCENE_OFF 0
 #endif
 static bool scene_fits_lds(const DevScene& sc) {
-    return !LDS_SCENE_OFF && sc.n_nodes != 0u && sc.nodes != nullptr && lds_scene_bytes(sc) <= LDS_SCENE_BYTES;
+    return !LDS_SCENE_OFF && sc.n_nodes != 0u && sc.n_nodes <= LDS_SCENE_NODES && sc.nodes != nullptr && lds_scene_bytes(sc) <= LDS_SCENE_BYTES;
 }
 
 static uint32_t auto_mode(const DevScene& sc, bool shadow) {

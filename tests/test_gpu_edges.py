@@ -309,12 +309,13 @@ def test_random_soups_against_brute_force(case, builder):
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), hex(tune)
 
 
-@pytest.mark.parametrize("n_tris,n_spheres", [(1, 0), (0, 1), (7, 1), (24, 1), (30, 0), (12, 6), (3, 9), (36, 2), (60, 0)])
+@pytest.mark.parametrize("n_tris,n_spheres", [(1, 0), (0, 1), (7, 1), (24, 1), (30, 0), (12, 6), (3, 9), (36, 2), (60, 6), (12, 21), (100, 40), (190, 0), (400, 0)])
 def test_small_scenes_against_brute_force(n_tris, n_spheres):
     """Scenes of a few dozen primitives: the refilling kernels traverse a copy of the hierarchy and the primitives
-    in LDS when it fits 2.5 KB (the first seven cases do, the last two do not) and the arrays in memory otherwise;
-    both, the one-ray-per-thread kernels and the automatic choice agree bit for bit with brute force, for both ray
-    classes (closest-hit camera and reflection rays, any-hit shadow rays to the point light)."""
+    in LDS when the hierarchy has at most 64 nodes and everything fits 16 KB (with 8 stack entries per ray in LDS
+    and the rest in scratch), and the arrays in memory otherwise (the last cases); both, the one-ray-per-thread
+    kernels and the automatic choice agree bit for bit with brute force, for both ray classes (closest-hit camera
+    and reflection rays, any-hit shadow rays to the point light)."""
     scene = soup(n_tris=n_tris, n_spheres=n_spheres, seed=100 + n_tris + n_spheres)
     b = Renderer(scene, options={_ffi.OPT_BRUTE_FORCE: 1})
     want_hits = b.primary_hits()
