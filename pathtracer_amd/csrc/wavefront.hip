@@ -799,13 +799,27 @@ __global__ __launch_bounds__(BLOCK) void k_extend_brute(RenderParams rp, DevScen
 
 // GROUP: within the block's span of the queue the hits are ordered by shading class, so
 // that (all but a few of) the surface kernel's waves see one primitive kind and one BRDF.
-template <bool GROUP>
+// TABLE (small scenes, at most CLASS_TABLE_PRIMS primitives): the block first writes the class of every primitive
+// into LDS, one byte each (triangle slots, then sphere slots), and a hit looks its class up there instead of
+// following two dependent loads (material id of the primitive, BRDF of the material) through the vector memory
+// pipeline.
+#define CLASS_TABLE_PRIMS 2048u
+template <bool GROUP, bool TABLE = false>
 __global__ __launch_bounds__(GEN_BLOCK) void k_compact_hits(RenderParams rp, DevScene sc, PathState ps, uint32_t count, uint32_t* __restrict__ hit_queue,
                                                         uint32_t* __restrict__ hit_count) {
     constexpr int NS = GROUP ? GEN_CHUNKS * HIT_CLASSES : GEN_CHUNKS;
     bool keep[NS];
     uint32_t at[NS], idx[GEN_CHUNKS], stream[GEN_CHUNKS];
     const bool bg = rp.bg[0] != 0.f || rp.bg[1] != 0.f || rp.bg[2] != 0.f;
+    __shared__ unsigned char cls_table[TABLE ? CLASS_TABLE_PRIMS : 1u];
+    if (TABLE) {
+        for (uint32_t k = threadIdx.x; k < sc.n_tris + sc.n_spheres; k += GEN_BLOCK) {
+            const bool tri = k < sc.n_tris;
+            const uint32_t mat = tri ? sc.tri_mat[k] : sc.sph_mat[k - sc.n_tris];
+            cls_table[k] = (unsigned char)((tri ? 0u : 2u) | (sc.materials[mat & ~MAT_LIGHT_BIT].brdf_type == PTC_GGX ? 1u : 0u));
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int k = 0; k < NS; ++k) keep[k] = false;
 #pragma unroll
@@ -817,7 +831,9 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_compact_hits(RenderParams rp, Dev
             const int ref = ps.hit_ref[i];
             if (ref != HIT_MISS) {
                 uint32_t cls = 0;
-                if (GROUP) {
+                if (GROUP && TABLE) {
+                    cls = cls_table[ref >= 0 ? (uint32_t)ref : sc.n_tris + (uint32_t)HIT_SPHERE_SLOT(ref)];
+                } else if (GROUP) {
                     const uint32_t mat = ref >= 0 ? sc.tri_mat[ref] : sc.sph_mat[HIT_SPHERE_SLOT(ref)];
                     cls = (ref >= 0 ? 0u : 2u) | (sc.materials[mat & ~MAT_LIGHT_BIT].brdf_type == PTC_GGX ? 1u : 0u);
                 }
@@ -1848,11 +1864,16 @@ uint32_t wf_resident_waves(int device) {
     return (uint32_t)per_cu * (uint32_t)cus * (BLOCK / 64);
 }
 
+#ifndef CLASS_TABLE_OFF
+#define CLASS_TABLE_OFF 0
+#endif
 // Queue of the paths whose extension ray hit something; misses end there.
 void wf_compact_hits(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, uint32_t count, uint32_t* hit_queue, uint32_t* hit_count) {
     if (count == 0) return;
     const dim3 g(blocks_for(count, GEN_BLOCK * GEN_CHUNKS)), b(GEN_BLOCK);
-    if (rp.group_hits) hipLaunchKernelGGL(k_compact_hits<true>, g, b, 0, s, rp, sc, ps, count, hit_queue, hit_count);
+    if (rp.group_hits && !CLASS_TABLE_OFF && sc.n_tris + sc.n_spheres <= CLASS_TABLE_PRIMS)
+        hipLaunchKernelGGL((k_compact_hits<true, true>), g, b, 0, s, rp, sc, ps, count, hit_queue, hit_count);
+    else if (rp.group_hits) hipLaunchKernelGGL(k_compact_hits<true>, g, b, 0, s, rp, sc, ps, count, hit_queue, hit_count);
     else hipLaunchKernelGGL(k_compact_hits<false>, g, b, 0, s, rp, sc, ps, count, hit_queue, hit_count);
 }
 
