@@ -102,6 +102,7 @@ struct DevScene {
     const BvhNode* nodes;       // nodes[0] = root
     const WideNode* wnodes;     // the same hierarchy with four children per node; null when not built
     uint32_t n_tris, n_spheres, n_nodes, n_wnodes;
+    uint32_t n_materials;       // entries of `materials`
     // lights
     const PtcPointLight* plights;
     const PtcDirectionalLight* dlights;

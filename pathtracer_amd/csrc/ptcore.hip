@@ -69,6 +69,7 @@ struct ptc_context {
     PtcTriangle* d_tris = nullptr;
     PtcSphere* d_spheres = nullptr;
     PtcMaterialValue* d_materials = nullptr;
+    uint32_t n_materials = 0;
     PtcPointLight* d_plights = nullptr;
     PtcDirectionalLight* d_dlights = nullptr;
     PtcQuadLight* d_qlights = nullptr;
@@ -316,6 +317,7 @@ DevScene deviceScene(const ptc_context* c) {
     sc.sph_mat = c->bvh.sph_mat;
     sc.sph_prim = c->bvh.sph_prim;
     sc.materials = c->d_materials;
+    sc.n_materials = c->n_materials;
     sc.nodes = c->bvh.nodes;
     sc.wnodes = c->bvh.wnodes;
     sc.n_wnodes = c->bvh.n_wnodes;
@@ -820,6 +822,7 @@ int ptc_build(ptc_context* ctx) try {
         ctx->mixed_hits = (int)seen[0] + seen[1] + seen[2] + seen[3] > 1;
     }
     CHK(upload(ctx->d_materials, mats, ctx->stream));
+    ctx->n_materials = (uint32_t)mats.size();
     CHK(upload(ctx->d_tris, ctx->tris, ctx->stream));
     CHK(upload(ctx->d_spheres, ctx->spheres, ctx->stream));
     bvh_free(ctx->bvh);

@@ -1422,14 +1422,27 @@ __device__ __forceinline__ vec3 gather_radiance(const RenderParams& rp, const De
 #define SURF_WAVES 5   /* waves per SIMD the register allocation aims at */
 #endif
 // One thread per path of the bounce that hit something.
-template <int INTEG>
-__global__ __launch_bounds__(SURF_BLOCK_MANY, SURF_WAVES) void k_surface(RenderParams rp, DevScene sc, PathState ps, const uint32_t* __restrict__ queue,
+// MATS: the material table (at most MAT_LDS_MAX de-duplicated records: any scene whose primitives share a few materials,
+// whatever its size) is copied into LDS by every block, and the material of a hit -- read at the light samples and again in
+// the closest-hit program, after stores the compiler must assume to alias it -- comes from there instead of through the
+// vector memory pipeline.
+#define MAT_LDS_MAX 24u
+#define MAT_WORDS (sizeof(PtcMaterialValue) / 4u)
+template <int INTEG, bool MATS = false>
+__global__ __launch_bounds__(SURF_BLOCK_MANY, SURF_WAVES) void k_surface(RenderParams rp, DevScene sc_global, PathState ps, const uint32_t* __restrict__ queue,
                                                        const uint32_t* __restrict__ count_ptr, uint32_t npix_pad, uint32_t sample_begin, uint32_t* __restrict__ segctr,
                                                        uint32_t* __restrict__ next_count,
                                                        uint32_t* __restrict__ gather_queue, uint32_t* __restrict__ gather_count,
                                                        uint32_t* __restrict__ shadow_count, uint32_t first_bounce) {
     const uint32_t count = *count_ptr;  // hits of this bounce, written by k_compact_hits
     if (blockIdx.x * blockDim.x >= count) return;
+    __shared__ uint32_t mat_copy[MATS ? MAT_LDS_MAX * MAT_WORDS : 1u];
+    DevScene sc = sc_global;
+    if (MATS) {
+        const uint32_t* g = reinterpret_cast<const uint32_t*>(sc_global.materials);
+        for (uint32_t k = threadIdx.x; k < sc_global.n_materials * MAT_WORDS; k += blockDim.x) mat_copy[k] = g[k];
+        sc.materials = reinterpret_cast<const PtcMaterialValue*>(mat_copy);
+    }
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool hit = i < count;
     bool sample = false, alive = false, gather = false;
@@ -1455,6 +1468,7 @@ __global__ __launch_bounds__(SURF_BLOCK_MANY, SURF_WAVES) void k_surface(RenderP
         hit_attributes(sc, ps.hit_ref[at_state], ps.hit_t[at_state], sg.o, sg.d, at);
         sample = rp.samples_per_path != 0u && samples_lights<INTEG>(rp, at.mat, sg.depth);
     }
+    if (MATS) __syncthreads();  // the material table is in place (the hit's own loads above were in flight beside the copy)
     // ---- the light samples: term + shadow ray each; a term that is exactly zero adds
     // nothing whether or not the ray is blocked, so no ray is queued for it; any other value
     // (NaN included) is stored and its ray queued; k_shadow zeroes the term of an occluded ray
@@ -1877,6 +1891,9 @@ void wf_compact_hits(hipStream_t s, const RenderParams& rp, const DevScene& sc, 
     else hipLaunchKernelGGL(k_compact_hits<false>, g, b, 0, s, rp, sc, ps, count, hit_queue, hit_count);
 }
 
+#ifndef MAT_LDS_OFF
+#define MAT_LDS_OFF 0
+#endif
 // `count_ptr` (device) holds the number of queued paths; `max_count` bounds it and sizes the grid.
 void wf_surface(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, const uint32_t* count_ptr,
                 uint32_t max_count, uint32_t npix_pad, uint32_t sample_begin, uint32_t* segctr, uint32_t* next_count,
@@ -1884,7 +1901,16 @@ void wf_surface(hipStream_t s, const RenderParams& rp, const DevScene& sc, const
     if (max_count == 0) return;
     const uint32_t block = rp.samples_per_path <= 2u ? SURF_BLOCK_FEW : SURF_BLOCK_MANY;
     const dim3 g(blocks_for(max_count, block)), b(block);
-#define PT_SURFACE(I) hipLaunchKernelGGL(k_surface<I>, g, b, 0, s, rp, sc, ps, queue, count_ptr, npix_pad, sample_begin, segctr, next_count, gather_queue, gather_count, shadow_count, first_bounce ? 1u : 0u)
+    const bool mats = !MAT_LDS_OFF && sc.n_materials != 0u && sc.n_materials <= MAT_LDS_MAX;
+#define PT_SURFACE(I)                                                                                                                                          \
+    do {                                                                                                                                                       \
+        if (mats)                                                                                                                                              \
+            hipLaunchKernelGGL((k_surface<I, true>), g, b, 0, s, rp, sc, ps, queue, count_ptr, npix_pad, sample_begin, segctr, next_count, gather_queue,      \
+                               gather_count, shadow_count, first_bounce ? 1u : 0u);                                                                            \
+        else                                                                                                                                                   \
+            hipLaunchKernelGGL((k_surface<I, false>), g, b, 0, s, rp, sc, ps, queue, count_ptr, npix_pad, sample_begin, segctr, next_count, gather_queue,     \
+                               gather_count, shadow_count, first_bounce ? 1u : 0u);                                                                            \
+    } while (0)
     switch (rp.integrator) {
         case INT_RAYTRACER: PT_SURFACE(INT_RAYTRACER); break;
         case INT_ANALYTICDIRECT: PT_SURFACE(INT_ANALYTICDIRECT); break;

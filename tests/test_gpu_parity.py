@@ -127,6 +127,25 @@ def test_pathtracer(rel, over, semantics, seeding):
     compare_render(load(rel, **over), semantics=semantics, seeding=seeding, bounce_cap=12, min_close=min_close)
 
 
+@pytest.mark.parametrize("n_materials", [3, 24, 25, 60])
+def test_many_materials(n_materials):
+    """The surface kernel reads a hit's material from a copy of the material table in LDS when the table has at
+    most 24 records and from memory otherwise: spheres of n distinct materials over a floor, next-event estimation
+    with one quad light, against the oracle on both sides of the limit."""
+    rng = np.random.default_rng(n_materials)
+    lines = ["size 96 72", "integrator pathtracer", "spp 4", "maxdepth 4", "nexteventestimation on", "camera 0 2 6 0 0.5 0 0 1 0 45",
+             "quadLight -1 4 -1 0 0 2 2 0 0 12 12 12", "maxverts 4", "vertex -6 0 -6", "vertex 6 0 -6", "vertex 6 0 6", "vertex -6 0 6",
+             "diffuse 0.6 0.6 0.6", "tri 0 2 1", "tri 0 3 2"]
+    for k in range(n_materials - 2):  # the floor and the light's own material are the other two
+        d, sp = rng.uniform(0.05, 0.8, 3), rng.uniform(0.0, 0.3, 3)
+        x, z = rng.uniform(-3, 3, 2)
+        lines += [f"diffuse {d[0]:.3f} {d[1]:.3f} {d[2]:.3f}", f"specular {sp[0]:.3f} {sp[1]:.3f} {sp[2]:.3f}", f"shininess {5 + 3 * k}",
+                  "brdf ggx" if k % 3 == 0 else "brdf phong", f"roughness {0.1 + 0.01 * k:.2f}", f"sphere {x:.3f} 0.4 {z:.3f} 0.4"]
+    scene = SceneLoader().loadText("\n".join(lines) + "\n")
+    st = compare_render(scene, semantics=1, seeding=1, bounce_cap=4)
+    assert st is not None
+
+
 def test_pathtracer2():
     scene = load("scene3/cornellNEE.test", size="96 96", spp="4", integrator="pathtracer2")
     compare_render(scene, semantics=0, seeding=1)
