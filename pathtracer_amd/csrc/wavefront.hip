@@ -1428,6 +1428,8 @@ __device__ __forceinline__ vec3 gather_radiance(const RenderParams& rp, const De
 // vector memory pipeline.
 #define MAT_LDS_MAX 24u
 #define MAT_WORDS (sizeof(PtcMaterialValue) / 4u)
+#define QLIGHT_LDS_MAX 8u   /* the quad lights travel with the materials: their corners are read once per light sample */
+#define QLIGHT_WORDS (sizeof(PtcQuadLight) / 4u)
 template <int INTEG, bool MATS = false>
 __global__ __launch_bounds__(SURF_BLOCK_MANY, SURF_WAVES) void k_surface(RenderParams rp, DevScene sc_global, PathState ps, const uint32_t* __restrict__ queue,
                                                        const uint32_t* __restrict__ count_ptr, uint32_t npix_pad, uint32_t sample_begin, uint32_t* __restrict__ segctr,
@@ -1437,11 +1439,15 @@ __global__ __launch_bounds__(SURF_BLOCK_MANY, SURF_WAVES) void k_surface(RenderP
     const uint32_t count = *count_ptr;  // hits of this bounce, written by k_compact_hits
     if (blockIdx.x * blockDim.x >= count) return;
     __shared__ uint32_t mat_copy[MATS ? MAT_LDS_MAX * MAT_WORDS : 1u];
+    __shared__ uint32_t qlight_copy[MATS ? QLIGHT_LDS_MAX * QLIGHT_WORDS : 1u];
     DevScene sc = sc_global;
     if (MATS) {
         const uint32_t* g = reinterpret_cast<const uint32_t*>(sc_global.materials);
         for (uint32_t k = threadIdx.x; k < sc_global.n_materials * MAT_WORDS; k += blockDim.x) mat_copy[k] = g[k];
         sc.materials = reinterpret_cast<const PtcMaterialValue*>(mat_copy);
+        const uint32_t* gq = reinterpret_cast<const uint32_t*>(sc_global.qlights);
+        for (uint32_t k = threadIdx.x; k < sc_global.n_qlights * QLIGHT_WORDS; k += blockDim.x) qlight_copy[k] = gq[k];
+        sc.qlights = reinterpret_cast<const PtcQuadLight*>(qlight_copy);
     }
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool hit = i < count;
@@ -1901,7 +1907,7 @@ void wf_surface(hipStream_t s, const RenderParams& rp, const DevScene& sc, const
     if (max_count == 0) return;
     const uint32_t block = rp.samples_per_path <= 2u ? SURF_BLOCK_FEW : SURF_BLOCK_MANY;
     const dim3 g(blocks_for(max_count, block)), b(block);
-    const bool mats = !MAT_LDS_OFF && sc.n_materials != 0u && sc.n_materials <= MAT_LDS_MAX;
+    const bool mats = !MAT_LDS_OFF && sc.n_materials != 0u && sc.n_materials <= MAT_LDS_MAX && sc.n_qlights <= QLIGHT_LDS_MAX;
 #define PT_SURFACE(I)                                                                                                                                          \
     do {                                                                                                                                                       \
         if (mats)                                                                                                                                              \
