@@ -92,6 +92,7 @@ def parse_args(argv=None):
     ap.add_argument("--builder", type=int, default=None, help="PTC_OPT_BVH_BUILDER")
     ap.add_argument("--tune", type=lambda v: int(v, 0), default=None, help="PTC_OPT_TUNE_TRAVERSAL value (experiments)")
     ap.add_argument("--sort-rays", type=int, default=None, help="PTC_OPT_SORT_RAYS (experiments)")
+    ap.add_argument("--opt", action="append", default=[], metavar="ID=VALUE", help="any other PTC_OPT_* by number (experiments), e.g. --opt 11=0")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal on a box with fewer GPUs than ranks: every rank renders on GPU 0 and the collectives run through gloo "
                          "on host copies (RCCL refuses a device that appears twice); the line then reports n_gpus 1 and the rank count")
@@ -227,6 +228,9 @@ def run_rank(args):
         opts[_ffi.OPT_BVH_BUILDER] = args.builder
     if args.sort_rays is not None:
         opts[_ffi.OPT_SORT_RAYS] = args.sort_rays
+    for kv in args.opt:
+        k, v = kv.split("=")
+        opts[int(k, 0)] = int(v, 0)
     r = Renderer(scene, device=local_rank, options=opts)
     sums = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda")
     r.bind_sum_buffer(sums.data_ptr(), sums.numel() * 4)
