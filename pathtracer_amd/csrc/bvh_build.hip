@@ -317,10 +317,12 @@ __global__ void k_ploc_scatter(const int* __restrict__ cluster_out, const int* _
     if (valid[i]) cluster_next[pos[i]] = cluster_out[i];
 }
 
-__global__ void k_pack_tris(const PtcTriangle* __restrict__ tris, const int32_t* __restrict__ slot_prim, uint32_t n, float4* __restrict__ tri_q) {
+__global__ void k_pack_tris(const PtcTriangle* __restrict__ tris, const int32_t* __restrict__ slot_prim, const uint32_t* __restrict__ tri_mat, uint32_t n,
+                            float4* __restrict__ tri_q, float4* __restrict__ tri_nm) {
     const uint32_t s = blockIdx.x * BB + threadIdx.x;
     if (s >= n) return;
     const PtcTriangle& t = tris[slot_prim[s]];
+    tri_nm[s] = make_float4(t.normal.x, t.normal.y, t.normal.z, __uint_as_float(tri_mat[s]));
     tri_q[3 * (size_t)s + 0] = make_float4(t.v1.x, t.v1.y, t.v1.z, t.normal.x);
     tri_q[3 * (size_t)s + 1] = make_float4(t.v2.x, t.v2.y, t.v2.z, t.normal.y);
     tri_q[3 * (size_t)s + 2] = make_float4(t.v3.x, t.v3.y, t.v3.z, t.normal.z);
@@ -1164,9 +1166,11 @@ std::string bvh_build(hipStream_t s, const BvhBuildInput& in, BvhBuildOutput& ou
     // one triangle more than the scene has: all zeros (no ray hits it), what the unused child slots of the wide nodes refer to
     HIPCHK(hipMalloc((void**)&out.tri_q, ((size_t)T + 1) * 3 * sizeof(float4)));
     HIPCHK(hipMalloc((void**)&out.tri_mat, ((size_t)T + 1) * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void**)&out.tri_nm, ((size_t)T + 1) * sizeof(float4)));
     HIPCHK(hipMalloc((void**)&out.tri_prim, ((size_t)T + 1) * sizeof(int32_t)));
     HIPCHK(hipMemsetAsync(out.tri_q + 3 * (size_t)T, 0, 3 * sizeof(float4), s));
     HIPCHK(hipMemsetAsync(out.tri_mat + T, 0, sizeof(uint32_t), s));
+    HIPCHK(hipMemsetAsync(out.tri_nm + T, 0, sizeof(float4), s));
     HIPCHK(hipMemsetAsync(out.tri_prim + T, 0, sizeof(int32_t), s));
     HIPCHK(hipMalloc((void**)&out.spheres, std::max<size_t>(S, 1) * sizeof(DevSphere)));
     HIPCHK(hipMalloc((void**)&out.sph_mat, std::max<size_t>(S, 1) * sizeof(uint32_t)));
@@ -1177,7 +1181,7 @@ std::string bvh_build(hipStream_t s, const BvhBuildInput& in, BvhBuildOutput& ou
     if (T) {
         HIPCHK(hipMemcpyAsync(out.tri_prim, kt.slot_prim.data(), sizeof(int32_t) * T, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(out.tri_mat, tmat.data(), sizeof(uint32_t) * T, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_pack_tris, dim3(nblocks(T)), dim3(BB), 0, s, in.d_tris, out.tri_prim, T, out.tri_q);
+        hipLaunchKernelGGL(k_pack_tris, dim3(nblocks(T)), dim3(BB), 0, s, in.d_tris, out.tri_prim, out.tri_mat, T, out.tri_q, out.tri_nm);
     }
     std::vector<DevSphere> hs(S);
     if (S) {
@@ -1249,7 +1253,7 @@ int bvh_collapse_wide_host(const BvhNode* bin, uint32_t n_nodes, WideNode* out, 
 }
 
 void bvh_free(BvhBuildOutput& o) {
-    for (void* p : {(void*)o.tri_q, (void*)o.tri_mat, (void*)o.tri_prim, (void*)o.spheres, (void*)o.sph_mat, (void*)o.sph_prim, (void*)o.nodes, (void*)o.wnodes})
+    for (void* p : {(void*)o.tri_q, (void*)o.tri_nm, (void*)o.tri_mat, (void*)o.tri_prim, (void*)o.spheres, (void*)o.sph_mat, (void*)o.sph_prim, (void*)o.nodes, (void*)o.wnodes})
         if (p) (void)hipFree(p);
     o = BvhBuildOutput();
 }

@@ -93,6 +93,7 @@ struct DevSphere {
 struct DevScene {
     // geometry (BVH leaf order)
     const float4* tri_q;        // 3 per triangle slot
+    const float4* tri_nm;       // 1 per triangle slot: normal.xyz, bits of tri_mat (the shading side's view of a triangle)
     const uint32_t* tri_mat;    // material id | MAT_LIGHT_BIT
     const int32_t* tri_prim;    // slot -> global primitive index
     const DevSphere* spheres;   // sphere slot order

@@ -109,15 +109,14 @@ struct HitAttr {
 
 __device__ __forceinline__ void hit_attributes(const DevScene& sc, int ref, float t, vec3 o, vec3 d, HitAttr& a) {
     if (ref >= 0) {  // Triangle.cu:48-58
-        const float4* q = sc.tri_q + 3 * (size_t)ref;
-        float4 q0 = q[0], q1 = q[1], q2 = q[2];
-        vec3 n = mk3(q0.w, q1.w, q2.w);
+        const float4 nm = sc.tri_nm[ref];  // the stored normal and the material word: one record, the vertices are not needed here
+        vec3 n = mk3(nm.x, nm.y, nm.z);
         if (dot(d, n) >= .0f) n = -n;
         float nDotWo = dot(n, -d);
         a.P = o + t * d;
         a.wo = -d;
         a.normal = nDotWo > 0 ? n : -n;
-        a.mat = sc.tri_mat[ref];
+        a.mat = __float_as_uint(nm.w);
     } else {  // Sphere.cu:45-56
         int s = HIT_SPHERE_SLOT(ref);
         const DevSphere& sp = sc.spheres[s];

@@ -311,6 +311,7 @@ void collectSpans(ptc_context* c) {  // stream must be idle
 DevScene deviceScene(const ptc_context* c) {
     DevScene sc{};
     sc.tri_q = c->bvh.tri_q;
+    sc.tri_nm = c->bvh.tri_nm;
     sc.tri_mat = c->bvh.tri_mat;
     sc.tri_prim = c->bvh.tri_prim;
     sc.spheres = c->bvh.spheres;
@@ -339,6 +340,7 @@ DevScene deviceSceneAny(const ptc_context* c) {
     DevScene sc = deviceScene(c);
     if (!c->two_trees) return sc;
     sc.tri_q = c->bvh_any.tri_q;
+    sc.tri_nm = c->bvh_any.tri_nm;
     sc.tri_mat = c->bvh_any.tri_mat;
     sc.tri_prim = c->bvh_any.tri_prim;
     sc.spheres = c->bvh_any.spheres;

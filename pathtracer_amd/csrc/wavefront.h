@@ -62,6 +62,7 @@ struct BvhBuildInput {
 
 struct BvhBuildOutput {  // device allocations owned by the caller afterwards
     float4* tri_q = nullptr;
+    float4* tri_nm = nullptr;    // per triangle slot: (normal.xyz, material word): all the surface kernel needs of a triangle, in one 16-byte record
     uint32_t* tri_mat = nullptr;
     int32_t* tri_prim = nullptr;
     DevSphere* spheres = nullptr;
