@@ -158,7 +158,7 @@ struct PathState {
     float4* g_thr;     //   throughput before the segment
     float* hit_t;      // closest-hit distance of the current segment
     int32_t* hit_ref;  // see HIT_*
-    float* contrib;    // 3 planes of [light sample][capacity]: per-shadow-sample f*G terms
+    float* contrib;    // [light sample][capacity] records of three floats: per-shadow-sample f*G terms
     float4* sh_o;      // queued shadow rays: origin.xyz, tmax
     float4* sh_d;      // direction.xyz, index of the ray's term in `contrib` (bits)
     uint32_t capacity;

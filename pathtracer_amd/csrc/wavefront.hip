@@ -340,6 +340,20 @@ __global__ __launch_bounds__(CAM_BLOCK) void k_generate(RenderParams rp, PathSta
 
 // ------------------------------------------------------------------ extend --
 
+// A light sample's term (the f*G value the reference adds when the shadow ray is unoccluded) lives in three consecutive
+// floats at index `slot` = sample * capacity + position of the segment in the bounce's hit queue: one 12-byte store or
+// load, and the lanes of a wave touch consecutive records.
+struct ContribRecord {
+    float x, y, z;
+};
+__device__ __forceinline__ void contrib_store(const PathState& ps, uint32_t slot, vec3 v) {
+    *reinterpret_cast<ContribRecord*>(ps.contrib + 3 * (size_t)slot) = ContribRecord{v.x, v.y, v.z};
+}
+__device__ __forceinline__ vec3 contrib_load(const PathState& ps, uint32_t slot) {
+    const ContribRecord r = *reinterpret_cast<const ContribRecord*>(ps.contrib + 3 * (size_t)slot);
+    return mk3(r.x, r.y, r.z);
+}
+
 // Work distribution of the two traversal kernels.  Each WAVE owns a span of
 // consecutive queue entries [pos, end) that it reserves from one global counter
 // (`wave_chunk` entries per atomic, so a few thousand atomics per launch); lanes
@@ -508,11 +522,8 @@ __global__ __launch_bounds__(BLOCK) void k_shadow_static(RenderParams rp, DevSce
     ClosestHit tmp;
     TravCounters cnt = {0u, 0u};
     if (traverse_simple<true, COUNT>(sc, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), rp.cf.epsilon, o4.w, stack + threadIdx.x, tmp, cnt)) {
-        const size_t plane = (size_t)rp.samples_per_path * ps.capacity;
         const uint32_t slot = f2u(d4.w);
-        ps.contrib[slot] = 0.f;
-        ps.contrib[slot + plane] = 0.f;
-        ps.contrib[slot + 2 * plane] = 0.f;
+        contrib_store(ps, slot, mk3(0.f));
     }
     if (COUNT) {
         atomicAdd(&trav_counters[2], (unsigned long long)cnt.nodes);
@@ -608,7 +619,6 @@ __global__ __launch_bounds__(BLOCK, DQ_MIN_WAVES) void k_trace_deferred(RenderPa
     uint32_t* my_stack = L.stack + tid;
     uint32_t* items = L.items[wave];
     uint32_t spill[DQ_SPILL];
-    const size_t plane = (size_t)rp.samples_per_path * ps.capacity;
     TravRay r;
     ClosestHit unused;
     TravCounters cnt = {0u, 0u};
@@ -651,9 +661,7 @@ __global__ __launch_bounds__(BLOCK, DQ_MIN_WAVES) void k_trace_deferred(RenderPa
             if (fin) {
                 if (ANY) {
                     if (L.best_ref[tid] != HIT_MISS) {
-                        ps.contrib[p] = 0.f;
-                        ps.contrib[p + plane] = 0.f;
-                        ps.contrib[p + 2 * plane] = 0.f;
+                        contrib_store(ps, p, mk3(0.f));
                     }
                 } else {
                     ps.hit_t[p] = u2f((uint32_t)(L.best[tid] >> 32));
@@ -871,7 +879,7 @@ __device__ __forceinline__ const PtcMaterialValue& material_of(const DevScene& s
 __device__ __forceinline__ bool is_light(uint32_t mat) { return (mat & MAT_LIGHT_BIT) != 0u; }
 
 // Position of light sample q's term for the segment at position `seg` of the bounce's hit
-// queue: three planes of samples_per_path * capacity floats.  (Everything that lives for
+// queue: samples_per_path * capacity records of three floats (contrib_store / contrib_load).  (Everything that lives for
 // one segment only -- these terms, the gather records -- is indexed by the hit-queue
 // position, which is dense, and not by the path number, whose live entries thin out with
 // every bounce.)
@@ -998,7 +1006,6 @@ __global__ __launch_bounds__(BLOCK) void k_shadow(RenderParams rp, DevScene sc_g
     const DevScene sc = scene_in_lds<LDS>(sc_global, scene_copy);
     const uint32_t count = *count_ptr;
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(shadow_total, (unsigned long long)count);
-    const size_t plane = (size_t)rp.samples_per_path * ps.capacity;
     uint32_t* my_stack = stack + threadIdx.x;
     uint32_t spill[TRAV_SPILL_STACK];
     TravRay r;
@@ -1028,9 +1035,7 @@ __global__ __launch_bounds__(BLOCK) void k_shadow(RenderParams rp, DevScene sc_g
                                                  : trav_round<true, COUNT, NS>(sc, r, my_stack, spill, sp, cur, best, cnt, occluded);
             if (fin) {
                 if (occluded) {
-                    ps.contrib[slot] = 0.f;
-                    ps.contrib[slot + plane] = 0.f;
-                    ps.contrib[slot + 2 * plane] = 0.f;
+                    contrib_store(ps, slot, mk3(0.f));
                 }
                 active = false;
             }
@@ -1051,11 +1056,8 @@ __global__ __launch_bounds__(BLOCK) void k_shadow_brute(RenderParams rp, DevScen
     const float4 o4 = ps.sh_o[i], d4 = ps.sh_d[i];
     ClosestHit tmp;
     if (brute_force<true>(sc, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), rp.cf.epsilon, o4.w, tmp)) {
-        const size_t plane = (size_t)rp.samples_per_path * ps.capacity;
         const uint32_t slot = f2u(d4.w);
-        ps.contrib[slot] = 0.f;
-        ps.contrib[slot + plane] = 0.f;
-        ps.contrib[slot + 2 * plane] = 0.f;
+        contrib_store(ps, slot, mk3(0.f));
     }
 }
 
@@ -1082,9 +1084,7 @@ struct SurfaceOut {
 };
 
 __device__ __forceinline__ vec3 contrib_at(const RenderParams& rp, const PathState& ps, uint32_t seg, uint32_t q) {
-    const size_t plane = (size_t)rp.samples_per_path * ps.capacity;
-    const float* c = ps.contrib + contrib_slot(ps, seg, q);
-    return mk3(c[0], c[plane], c[2 * plane]);
+    return contrib_load(ps, contrib_slot(ps, seg, q));
 }
 
 // Sum of the light-sample terms of quad light k in loop order.
@@ -1487,7 +1487,6 @@ __global__ __launch_bounds__(SURF_BLOCK_MANY, SURF_WAVES) void k_surface(RenderP
     uint32_t f_slot[2] = {0u, 0u};
     bool f_need[2] = {false, false};
     if (INTEG != INT_ANALYTICDIRECT) {
-        const size_t plane = (size_t)rp.samples_per_path * ps.capacity;
         if (few) {
 #pragma unroll
             for (uint32_t q = 0; q < 2u; ++q) {
@@ -1496,9 +1495,7 @@ __global__ __launch_bounds__(SURF_BLOCK_MANY, SURF_WAVES) void k_surface(RenderP
                     const vec3 term = light_sample<INTEG>(rp, sc, at, material_of(sc, at.mat), sg.seed, q, f_o[q], f_d[q], f_tmax[q]);
                     f_need[q] = !(term.x == 0.f && term.y == 0.f && term.z == 0.f);
                     f_slot[q] = contrib_slot(ps, i, q);
-                    ps.contrib[f_slot[q]] = term.x;
-                    ps.contrib[f_slot[q] + plane] = term.y;
-                    ps.contrib[f_slot[q] + 2 * plane] = term.z;
+                    contrib_store(ps, f_slot[q], term);
                 }
             }
         } else {
@@ -1522,9 +1519,7 @@ __global__ __launch_bounds__(SURF_BLOCK_MANY, SURF_WAVES) void k_surface(RenderP
                         const vec3 term = light_sample<INTEG>(rp, sc, at, material_of(sc, at.mat), sg.seed, q, sh_o[k], sh_d[k], sh_tmax[k]);
                         need_ray[k] = !(term.x == 0.f && term.y == 0.f && term.z == 0.f);
                         slot[k] = contrib_slot(ps, i, q);
-                        ps.contrib[slot[k]] = term.x;
-                        ps.contrib[slot[k] + plane] = term.y;
-                        ps.contrib[slot[k] + 2 * plane] = term.z;
+                        contrib_store(ps, slot[k], term);
                     }
                 }
                 queue_reserve_streams<MANY_STEP>(need_ray, shadow_count, at_);
