@@ -573,7 +573,7 @@ int renderRange(ptc_context* ctx, int frame_id, uint32_t w, uint32_t h, int32_t 
         if (S) per_batch = std::max<uint64_t>(1u, std::min<uint64_t>(per_batch, 0xFFFFFF00ull / ((uint64_t)ctx->npix_pad * S)));
     }
     per_batch = std::min<uint64_t>(per_batch, (uint64_t)std::max(1, j1 - j0));
-    if ((uint64_t)ctx->npix_pad * per_batch > 0xFFFFFFF0ull) return fail(ctx, PTC_ERR_INVALID, "batch too large");
+    if ((uint64_t)ctx->npix_pad * per_batch > 0x7FFFFFF0ull) return fail(ctx, PTC_ERR_INVALID, "batch too large");  // path numbers keep their top bit free (gather records)
     rc = ensurePaths(ctx, (uint32_t)(ctx->npix_pad * per_batch), S);
     if (rc) return rc;
     ctx->stats.batch_paths = std::max<uint64_t>(ctx->stats.batch_paths, ctx->npix_pad * per_batch);
@@ -912,7 +912,7 @@ int ptc_render_range_static(ptc_context* ctx, int frame_id, uint32_t width, uint
     uint64_t per_batch = rp.seeding == 0 ? 1u : std::max<uint64_t>(1u, std::min<uint64_t>(ctx->batch_paths / npix_pad, (uint64_t)std::max(1, spp_end - spp_begin)));
     const uint64_t room = PTC_STATIC_SCRATCH_BYTES > head ? (PTC_STATIC_SCRATCH_BYTES - head) / (bytesPerPath(S) + 1u) : 0u;  // paths, roughly
     per_batch = std::min<uint64_t>(per_batch, std::max<uint64_t>(1u, room / npix_pad));
-    while (per_batch > 1u && (npix_pad * per_batch > 0xFFFFFFF0ull || head + carvePaths(nullptr, (uint32_t)(npix_pad * per_batch), S, ps, hq, gq) > PTC_STATIC_SCRATCH_BYTES)) --per_batch;
+    while (per_batch > 1u && (npix_pad * per_batch > 0x7FFFFFF0ull || head + carvePaths(nullptr, (uint32_t)(npix_pad * per_batch), S, ps, hq, gq) > PTC_STATIC_SCRATCH_BYTES)) --per_batch;
     if (npix_pad > 0xFFFFF000ull || (S && npix_pad * S > 0xFFFFFF00ull) ||
         head + carvePaths(nullptr, (uint32_t)npix_pad, S, ps, hq, gq) > PTC_STATIC_SCRATCH_BYTES)
         return fail(ctx, PTC_ERR_INVALID, "image too large for the static scratch (" + std::to_string(PTC_STATIC_SCRATCH_MIB) + " MiB): one sample of every pixel of the image, padded to 64x64 blocks, needs " +

@@ -1411,6 +1411,7 @@ __device__ __forceinline__ vec3 gather_radiance(const RenderParams& rp, const De
     return a;
 }
 
+#define GATHER_WITH_LE 0x80000000u   /* top bit of the fourth word of a gather record (PathState::g_a); the rest is the path number */
 // Threads per block of k_surface.  With one or two light samples per hit: 256 (measured 256 > 512 by
 // 1-3 % > 1024 by 4 % more >> 128).  With many samples per hit every sample takes one queue atomic
 // per block, and the rate of atomics on one word (about 88 per microsecond) bounds the kernel: 1024.
@@ -1546,8 +1547,10 @@ __global__ __launch_bounds__(SURF_BLOCK_MANY, SURF_WAVES) void k_surface(RenderP
         gather = out.gather && sample;
         if (gather) {
             // w: does the first-hit rule of pathTracer include the emission (:900-903)
-            ps.g_a[i] = make_float4(out.a.x, out.a.y, out.a.z, u2f((!rp.cf.next_event_est || depth_before == 0u) ? 1u : 0u));
-            ps.g_thr[i] = make_float4(thr_before.x, thr_before.y, thr_before.z, u2f(p));
+            // fourth word: the path number, and in its top bit whether the first-hit rule of pathTracer includes the emission (:900-903)
+            ps.g_a[i] = make_float4(out.a.x, out.a.y, out.a.z, u2f(p | ((!rp.cf.next_event_est || depth_before == 0u) ? GATHER_WITH_LE : 0u)));
+            // the throughput before the segment; camera segments all have (1, 1, 1): nothing is stored for them
+            if (!first_bounce) ps.g_thr[i] = make_float4(thr_before.x, thr_before.y, thr_before.z, 0.f);
         } else {
             // gather wanted but there is not a single light sample (lightsamples 0): the same
             // formulas over zero terms, here
@@ -1616,10 +1619,11 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(RenderParams rp, DevSce
     const uint32_t i = blockIdx.x * GATHER_BLOCK + threadIdx.x;
     if (i >= *gather_count) return;
     const uint32_t seg = gather_queue[i];  // position in the hit queue
-    const float4 a4 = ps.g_a[seg], t4 = ps.g_thr[seg];
-    const uint32_t p = f2u(t4.w);
+    const float4 a4 = ps.g_a[seg];
+    const float4 t4 = rp.camera_rays ? make_float4(1.f, 1.f, 1.f, 0.f) : ps.g_thr[seg];
+    const uint32_t p = f2u(a4.w) & ~GATHER_WITH_LE;
     const vec3 a = mk3(a4.x, a4.y, a4.z), thr = mk3(t4.x, t4.y, t4.z);
-    const vec3 radiance = gather_radiance<INTEG>(rp, sc, ps, seg, a, thr, f2u(a4.w) != 0u);
+    const vec3 radiance = gather_radiance<INTEG>(rp, sc, ps, seg, a, thr, (f2u(a4.w) & GATHER_WITH_LE) != 0u);
     float4 L = rp.init_L ? make_float4(0.f, 0.f, 0.f, 0.f) : ps.L[p];
     L.x += radiance.x;  // PinholeCamera.cu:61
     L.y += radiance.y;
