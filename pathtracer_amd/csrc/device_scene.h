@@ -147,8 +147,8 @@ struct RenderParams {
 struct PathState {
     float4* o_seed;    // origin.xyz, seed of the coming segment (bits)
     float4* d_depth;   // direction.xyz, depth (bits)
-    float4* thr;       // throughput.xyz, segment number within the path (bits)
-    uint32_t* pid;     // path number: ((tile * samples in batch + sample) * 64 + pixel within its 8x8 tile)
+    float4* thr;       // throughput.xyz, path number (bits); camera segments have none (throughput 1, path number in `pid`)
+    uint32_t* pid;     // path number of the camera segments: ((tile * samples in batch + sample) * 64 + pixel within its 8x8 tile)
     float4* o_seed_next;
     float4* d_depth_next;
     float4* thr_next;

@@ -1107,7 +1107,7 @@ int ptc_probe_segments(ptc_context* ctx, uint32_t n, const PtcSegmentProbe* in, 
     for (uint32_t i = 0; i < n; ++i) {
         o[i] = make_float4(in[i].o[0], in[i].o[1], in[i].o[2], bits(in[i].seed));
         d[i] = make_float4(in[i].d[0], in[i].d[1], in[i].d[2], bits(in[i].depth));
-        t[i] = make_float4(in[i].thr[0], in[i].thr[1], in[i].thr[2], bits(in[i].depth));  // segment number = depth
+        t[i] = make_float4(in[i].thr[0], in[i].thr[1], in[i].thr[2], bits(i));  // path number = probe number
         pid[i] = i;
     }
     hipStream_t s = ctx->stream;
@@ -1139,7 +1139,6 @@ int ptc_probe_segments(ptc_context* ctx, uint32_t n, const PtcSegmentProbe* in, 
         CHK(hipMemcpyAsync(o.data(), ctx->ps.o_seed, alive_n * sizeof(float4), hipMemcpyDeviceToHost, s));
         CHK(hipMemcpyAsync(d.data(), ctx->ps.d_depth, alive_n * sizeof(float4), hipMemcpyDeviceToHost, s));
         CHK(hipMemcpyAsync(t.data(), ctx->ps.thr, alive_n * sizeof(float4), hipMemcpyDeviceToHost, s));
-        CHK(hipMemcpyAsync(pid.data(), ctx->ps.pid, alive_n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     }
     CHK(hipStreamSynchronize(s));
     (void)hipFree(tmp);
@@ -1153,8 +1152,10 @@ int ptc_probe_segments(ptc_context* ctx, uint32_t n, const PtcSegmentProbe* in, 
         out[i].t = ht[i];
     }
     for (uint32_t k = 0; k < alive_n; ++k) {
-        if (pid[k] >= n) return fail(ctx, PTC_ERR_DEVICE, "probe: survivor with a bad path number");
-        PtcSegmentResult& r = out[pid[k]];
+        uint32_t path = 0;
+        std::memcpy(&path, &t[k].w, 4);
+        if (path >= n) return fail(ctx, PTC_ERR_DEVICE, "probe: survivor with a bad path number");
+        PtcSegmentResult& r = out[path];
         r.alive = 1;
         r.o[0] = o[k].x; r.o[1] = o[k].y; r.o[2] = o[k].z;
         r.d[0] = d[k].x; r.d[1] = d[k].y; r.d[2] = d[k].z;

@@ -847,7 +847,7 @@ __global__ __launch_bounds__(GEN_BLOCK) void k_compact_hits(RenderParams rp, Dev
                 }
                 stream[c] = cls * GEN_CHUNKS + c;
             } else if (bg || rp.init_L) {
-                const uint32_t p = ps.pid[i];
+                const uint32_t p = rp.camera_rays ? ps.pid[i] : f2u(ps.thr[i].w);
                 float4 L = rp.init_L ? make_float4(0.f, 0.f, 0.f, 0.f) : ps.L[p];
                 L.x += rp.bg[0];
                 L.y += rp.bg[1];
@@ -1460,18 +1460,25 @@ __global__ __launch_bounds__(SURF_BLOCK_MANY, SURF_WAVES) void k_surface(RenderP
     float4 n_o = make_float4(0.f, 0.f, 0.f, 0.f), n_d = n_o, n_t = n_o;  // state of the next segment
     if (hit) {
         at_state = queue[i];
-        p = ps.pid[at_state];
-        // camera segments: throughput 1, segment 0 (k_generate does not write them)
+        // camera segments: throughput 1 (k_generate does not write it), path number in an array of its own; later
+        // segments carry the path number in the fourth word of their throughput record
         float4 o4, d4;
         load_segment(rp, ps, at_state, o4, d4);
-        const float4 t4 = first_bounce ? make_float4(1.f, 1.f, 1.f, u2f(0u)) : ps.thr[at_state];
+        float4 t4;
+        if (first_bounce) {
+            t4 = make_float4(1.f, 1.f, 1.f, 0.f);
+            p = ps.pid[at_state];
+        } else {
+            t4 = ps.thr[at_state];
+            p = f2u(t4.w);
+        }
         sg.o = mk3(o4.x, o4.y, o4.z);
         sg.d = mk3(d4.x, d4.y, d4.z);
         sg.thr = mk3(t4.x, t4.y, t4.z);
         sg.seed = f2u(o4.w);
         sg.depth = f2u(d4.w);
         sg.done = false;
-        bounce = f2u(t4.w);
+        bounce = sg.depth;  // a live path has gained one unit of depth per segment (every integrator's survivors do `depth++` once)
         hit_attributes(sc, ps.hit_ref[at_state], ps.hit_t[at_state], sg.o, sg.d, at);
         sample = rp.samples_per_path != 0u && samples_lights<INTEG>(rp, at.mat, sg.depth);
     }
@@ -1583,7 +1590,7 @@ __global__ __launch_bounds__(SURF_BLOCK_MANY, SURF_WAVES) void k_surface(RenderP
         const uint32_t seed = segment_seed(rp, key0, sample, bounce, segctr, pix);
         n_o = make_float4(sg.o.x, sg.o.y, sg.o.z, u2f(seed));
         n_d = make_float4(sg.d.x, sg.d.y, sg.d.z, u2f(sg.depth));
-        n_t = make_float4(sg.thr.x, sg.thr.y, sg.thr.z, u2f(bounce));
+        n_t = make_float4(sg.thr.x, sg.thr.y, sg.thr.z, u2f(p));
     }
     uint32_t next_at = 0;  // the survivor's position in the next bounce's (packed) path state
     if (few) {
@@ -1605,7 +1612,6 @@ __global__ __launch_bounds__(SURF_BLOCK_MANY, SURF_WAVES) void k_surface(RenderP
         ps.o_seed_next[next_at] = n_o;
         ps.d_depth_next[next_at] = n_d;
         ps.thr_next[next_at] = n_t;
-        ps.pid_next[next_at] = p;
     }
 }
 
