@@ -152,7 +152,6 @@ struct PathState {
     float4* o_seed_next;
     float4* d_depth_next;
     float4* thr_next;
-    uint32_t* pid_next;
     float4* L;         // radiance accumulated by this path
     float4* g_a;       // segments waiting for their light terms: constant part, emission flag (bits)
     float4* g_thr;     //   throughput before the segment

@@ -228,7 +228,6 @@ size_t carvePaths(char* base, uint32_t capacity, uint32_t S, PathState& ps, uint
     ps.o_seed_next = (float4*)take(n * sizeof(float4));
     ps.d_depth_next = (float4*)take(n * sizeof(float4));
     ps.thr_next = (float4*)take(n * sizeof(float4));
-    ps.pid_next = (uint32_t*)take(n * sizeof(uint32_t));
     hitq = (uint32_t*)take(n * sizeof(uint32_t));
     gatherq = (uint32_t*)take(n * sizeof(uint32_t));
     ps.capacity = capacity;
@@ -237,7 +236,7 @@ size_t carvePaths(char* base, uint32_t capacity, uint32_t S, PathState& ps, uint
 
 // Device memory one path of a batch takes (see carvePaths): the packed state twice, L, hit, gather
 // record, two queue entries, and per light sample its term and its shadow-ray record.
-uint64_t bytesPerPath(uint32_t S) { return 2u * (48u + 4u) + 16u + 8u + 32u + 8u + (uint64_t)S * (12u + 32u); }
+uint64_t bytesPerPath(uint32_t S) { return 2u * 48u + 4u + 16u + 8u + 32u + 8u + (uint64_t)S * (12u + 32u); }
 
 int ensurePaths(ptc_context* ctx, uint32_t capacity, uint32_t contrib_samples) {
     if (ctx->ps.capacity >= capacity && ctx->contrib_samples >= contrib_samples) return PTC_OK;
@@ -446,7 +445,6 @@ int runBounces(ptc_context* ctx, const RenderParams& rp_frame, const DevScene& s
             std::swap(ctx->ps.o_seed, ctx->ps.o_seed_next);
             std::swap(ctx->ps.d_depth, ctx->ps.d_depth_next);
             std::swap(ctx->ps.thr, ctx->ps.thr_next);
-            std::swap(ctx->ps.pid, ctx->ps.pid_next);
         }
         {
             Timed t(ctx, 0);
@@ -496,7 +494,6 @@ int runBounces(ptc_context* ctx, const RenderParams& rp_frame, const DevScene& s
         std::swap(ctx->ps.o_seed, ctx->ps.o_seed_next);
         std::swap(ctx->ps.d_depth, ctx->ps.d_depth_next);
         std::swap(ctx->ps.thr, ctx->ps.thr_next);
-        std::swap(ctx->ps.pid, ctx->ps.pid_next);
         ++bounce;
     }
     if (gather_pending) CHK(hipStreamWaitEvent(ctx->stream, ctx->ev_gather, 0));

@@ -45,8 +45,7 @@ __global__ __launch_bounds__(RS_BLOCK) void k_ray_permute(PathState ps, uint32_t
     const uint32_t from = order[i];
     ps.o_seed_next[i] = ps.o_seed[from];
     ps.d_depth_next[i] = ps.d_depth[from];
-    ps.thr_next[i] = ps.thr[from];
-    ps.pid_next[i] = ps.pid[from];
+    ps.thr_next[i] = ps.thr[from];  // carries the path number (only camera segments keep it in `pid`, and those are never sorted)
 }
 
 }  // namespace
