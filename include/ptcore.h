@@ -157,7 +157,7 @@ enum {
      * the image, and limited to what fits in half of the free device memory at about
      * 170 + 44 x light samples bytes per path). Default 536870912 (about 140 GB with two
      * light samples per segment): fewer, larger launches per frame.  A batch holds fewer
-     * than 2^31 paths whatever is asked for. */
+     * than 2^30 paths whatever is asked for. */
     PTC_OPT_BATCH_PATHS = 5,
     /* 1 = bracket every kernel class with HIP events and sum the times. */
     PTC_OPT_PROFILE = 6,
@@ -256,7 +256,7 @@ int  ptc_render_range(ptc_context* ctx, int frame_id, uint32_t width, uint32_t h
  * caller's `sums_device` (device memory, width*height*3 floats, same indexing as ptc_read_sum; cleared
  * first when clear != 0); the context's own sum buffer and result are not touched.  The stream is
  * synchronised before the call returns.  One sample of every pixel of the image, padded to whole 64x64
- * pixel blocks, must fit: (172 + 44 x light samples per segment) bytes per padded pixel, i.e. up to
+ * pixel blocks, must fit: (176 + 44 x light samples per segment) bytes per padded pixel, i.e. up to
  * 384x448 pixels with two quad lights; larger images -> PTC_ERR_INVALID with a message that
  * says so.  Scene, lights and options must be set up (ptc_set_*, ptc_build) before, with the ordinary
  * calls.  With reference seeding the range must start at 0 with clear (no per-pixel history is kept

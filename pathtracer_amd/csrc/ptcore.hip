@@ -217,6 +217,7 @@ size_t carvePaths(char* base, uint32_t capacity, uint32_t S, PathState& ps, uint
     ps.d_depth = (float4*)take(n * sizeof(float4));
     ps.thr = (float4*)take(n * sizeof(float4));
     ps.L = (float4*)take(n * sizeof(float4));
+    ps.g_p = (uint32_t*)take(n * sizeof(uint32_t));
     ps.g_a = (float4*)take(n * sizeof(float4));
     ps.g_thr = (float4*)take(n * sizeof(float4));
     ps.hit_t = (float*)take(n * sizeof(float));
@@ -236,7 +237,7 @@ size_t carvePaths(char* base, uint32_t capacity, uint32_t S, PathState& ps, uint
 
 // Device memory one path of a batch takes (see carvePaths): the packed state twice, L, hit, gather
 // record, two queue entries, and per light sample its term and its shadow-ray record.
-uint64_t bytesPerPath(uint32_t S) { return 2u * 48u + 4u + 16u + 8u + 32u + 8u + (uint64_t)S * (12u + 32u); }
+uint64_t bytesPerPath(uint32_t S) { return 2u * 48u + 4u + 16u + 8u + 4u + 32u + 8u + (uint64_t)S * (12u + 32u); }
 
 int ensurePaths(ptc_context* ctx, uint32_t capacity, uint32_t contrib_samples) {
     if (ctx->ps.capacity >= capacity && ctx->contrib_samples >= contrib_samples) return PTC_OK;
@@ -570,7 +571,8 @@ int renderRange(ptc_context* ctx, int frame_id, uint32_t w, uint32_t h, int32_t 
         if (S) per_batch = std::max<uint64_t>(1u, std::min<uint64_t>(per_batch, 0xFFFFFF00ull / ((uint64_t)ctx->npix_pad * S)));
     }
     per_batch = std::min<uint64_t>(per_batch, (uint64_t)std::max(1, j1 - j0));
-    if ((uint64_t)ctx->npix_pad * per_batch > 0x7FFFFFF0ull) return fail(ctx, PTC_ERR_INVALID, "batch too large");  // path numbers keep their top bit free (gather records)
+    per_batch = std::max<uint64_t>(1u, std::min<uint64_t>(per_batch, 0x3FFFFFF0ull / ctx->npix_pad));
+    if ((uint64_t)ctx->npix_pad * per_batch > 0x3FFFFFF0ull) return fail(ctx, PTC_ERR_INVALID, "batch too large");  // path numbers keep their top two bits free (gather records)
     rc = ensurePaths(ctx, (uint32_t)(ctx->npix_pad * per_batch), S);
     if (rc) return rc;
     ctx->stats.batch_paths = std::max<uint64_t>(ctx->stats.batch_paths, ctx->npix_pad * per_batch);
@@ -909,7 +911,7 @@ int ptc_render_range_static(ptc_context* ctx, int frame_id, uint32_t width, uint
     uint64_t per_batch = rp.seeding == 0 ? 1u : std::max<uint64_t>(1u, std::min<uint64_t>(ctx->batch_paths / npix_pad, (uint64_t)std::max(1, spp_end - spp_begin)));
     const uint64_t room = PTC_STATIC_SCRATCH_BYTES > head ? (PTC_STATIC_SCRATCH_BYTES - head) / (bytesPerPath(S) + 1u) : 0u;  // paths, roughly
     per_batch = std::min<uint64_t>(per_batch, std::max<uint64_t>(1u, room / npix_pad));
-    while (per_batch > 1u && (npix_pad * per_batch > 0x7FFFFFF0ull || head + carvePaths(nullptr, (uint32_t)(npix_pad * per_batch), S, ps, hq, gq) > PTC_STATIC_SCRATCH_BYTES)) --per_batch;
+    while (per_batch > 1u && (npix_pad * per_batch > 0x3FFFFFF0ull || head + carvePaths(nullptr, (uint32_t)(npix_pad * per_batch), S, ps, hq, gq) > PTC_STATIC_SCRATCH_BYTES)) --per_batch;
     if (npix_pad > 0xFFFFF000ull || (S && npix_pad * S > 0xFFFFFF00ull) ||
         head + carvePaths(nullptr, (uint32_t)npix_pad, S, ps, hq, gq) > PTC_STATIC_SCRATCH_BYTES)
         return fail(ctx, PTC_ERR_INVALID, "image too large for the static scratch (" + std::to_string(PTC_STATIC_SCRATCH_MIB) + " MiB): one sample of every pixel of the image, padded to 64x64 blocks, needs " +

@@ -1411,7 +1411,8 @@ __device__ __forceinline__ vec3 gather_radiance(const RenderParams& rp, const De
     return a;
 }
 
-#define GATHER_WITH_LE 0x80000000u   /* top bit of the fourth word of a gather record (PathState::g_a); the rest is the path number */
+#define GATHER_WITH_LE 0x80000000u   /* bits of a segment's word in PathState::g_p beside the path number */
+#define GATHER_A_SET 0x40000000u
 // Threads per block of k_surface.  With one or two light samples per hit: 256 (measured 256 > 512 by
 // 1-3 % > 1024 by 4 % more >> 128).  With many samples per hit every sample takes one queue atomic
 // per block, and the rate of atomics on one word (about 88 per microsecond) bounds the kernel: 1024.
@@ -1554,8 +1555,13 @@ __global__ __launch_bounds__(SURF_BLOCK_MANY, SURF_WAVES) void k_surface(RenderP
         gather = out.gather && sample;
         if (gather) {
             // w: does the first-hit rule of pathTracer include the emission (:900-903)
-            // fourth word: the path number, and in its top bit whether the first-hit rule of pathTracer includes the emission (:900-903)
-            ps.g_a[i] = make_float4(out.a.x, out.a.y, out.a.z, u2f(p | ((!rp.cf.next_event_est || depth_before == 0u) ? GATHER_WITH_LE : 0u)));
+            // one word per waiting segment: the path number, whether the first-hit rule of pathTracer includes the emission
+            // (:900-903), and whether the constant part is anything but +0 -- it rarely is (the emission of the surface at a
+            // first hit, nothing later with next-event estimation), and only then is its record written and read
+            const bool a_set = !(out.a.x == 0.f && out.a.y == 0.f && out.a.z == 0.f) || __builtin_signbitf(out.a.x) || __builtin_signbitf(out.a.y) ||
+                               __builtin_signbitf(out.a.z);
+            ps.g_p[i] = p | ((!rp.cf.next_event_est || depth_before == 0u) ? GATHER_WITH_LE : 0u) | (a_set ? GATHER_A_SET : 0u);
+            if (a_set) ps.g_a[i] = make_float4(out.a.x, out.a.y, out.a.z, 0.f);
             // the throughput before the segment; camera segments all have (1, 1, 1): nothing is stored for them
             if (!first_bounce) ps.g_thr[i] = make_float4(thr_before.x, thr_before.y, thr_before.z, 0.f);
         } else {
@@ -1625,11 +1631,12 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(RenderParams rp, DevSce
     const uint32_t i = blockIdx.x * GATHER_BLOCK + threadIdx.x;
     if (i >= *gather_count) return;
     const uint32_t seg = gather_queue[i];  // position in the hit queue
-    const float4 a4 = ps.g_a[seg];
+    const uint32_t word = ps.g_p[seg];
+    const float4 a4 = (word & GATHER_A_SET) ? ps.g_a[seg] : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 t4 = rp.camera_rays ? make_float4(1.f, 1.f, 1.f, 0.f) : ps.g_thr[seg];
-    const uint32_t p = f2u(a4.w) & ~GATHER_WITH_LE;
+    const uint32_t p = word & ~(GATHER_WITH_LE | GATHER_A_SET);
     const vec3 a = mk3(a4.x, a4.y, a4.z), thr = mk3(t4.x, t4.y, t4.z);
-    const vec3 radiance = gather_radiance<INTEG>(rp, sc, ps, seg, a, thr, (f2u(a4.w) & GATHER_WITH_LE) != 0u);
+    const vec3 radiance = gather_radiance<INTEG>(rp, sc, ps, seg, a, thr, (word & GATHER_WITH_LE) != 0u);
     float4 L = rp.init_L ? make_float4(0.f, 0.f, 0.f, 0.f) : ps.L[p];
     L.x += radiance.x;  // PinholeCamera.cu:61
     L.y += radiance.y;
