@@ -381,7 +381,7 @@ def cpu_baseline(args, scene):
             spp *= 2
     st, stride, spp = best
     return {"value": round(st.extension_rays / st.seconds / 1e6, 3), "unit": "Mrays/s", "cores": threads, "nproc": nproc, "kind": "port",
-            "sample": f"every {stride}th pixel in x and y, {spp} spp, same scene and options; {st.extension_rays} extension + {st.shadow_rays} shadow rays in {st.seconds:.1f} s (incl. CPU BVH build); "
+            "sample": ("every pixel" if stride == 1 else f"every {stride}th pixel in x and y") + f", {spp} spp, same scene and options; {st.extension_rays} extension + {st.shadow_rays} shadow rays in {st.seconds:.1f} s (incl. CPU BVH build); "
                       f"{threads} threads = this job's CPU share (OMP_NUM_THREADS) of the machine's {nproc} hardware threads"}
 
 
