@@ -124,9 +124,12 @@ enum {
     PTC_ERR_DEVICE       = -3,  /* HIP error (message has the HIP string)      */
     PTC_ERR_UNSUPPORTED  = -4,  /* scene uses a feature outside the built path */
     PTC_ERR_NOT_BUILT    = -5,  /* render before ptc_build                     */
-    PTC_ERR_HOST         = -6   /* host-side failure (out of memory, a thread
+    PTC_ERR_HOST         = -6,  /* host-side failure (out of memory, a thread
                                    that could not start): no exception leaves
                                    the library                                 */
+    PTC_ERR_NOMEM        = -7,  /* the device is out of memory                 */
+    PTC_ERR_BUSY         = -8   /* ptc_render_range_static: another call is
+                                   using this GPU's static scratch             */
 };
 
 /* ---------------------------------------------------------------- options -- */
@@ -248,20 +251,25 @@ int  ptc_render(ptc_context* ctx, int frame_id, uint32_t width, uint32_t height)
  * ptc_synchronize (or any later operation on the same stream). */
 int  ptc_render_range(ptc_context* ctx, int frame_id, uint32_t width, uint32_t height,
                       int32_t spp_begin, int32_t spp_end, int clear);
-/* No counterpart in the reference.  For callers that cannot allocate device memory (code under HIP
- * graph capture, tight serving loops, harnesses that forbid hipMalloc): ptc_render_range with every
+/* No counterpart in the reference.  For callers that cannot allocate device memory (tight serving loops,
+ * harnesses that forbid hipMalloc, code that runs between the captures of HIP graphs): ptc_render_range with every
  * per-path and per-pixel work array taken from a fixed array in device memory that the library holds on
  * each GPU it runs on (PTC_STATIC_SCRATCH_MIB MiB, until the process ends) instead of from allocations.
  * The call allocates and frees nothing.  Samples [spp_begin, spp_end) of every pixel are added to the
  * caller's `sums_device` (device memory, width*height*3 floats, same indexing as ptc_read_sum; cleared
- * first when clear != 0); the context's own sum buffer and result are not touched.  The stream is
- * synchronised before the call returns.  One sample of every pixel of the image, padded to whole 64x64
+ * first when clear != 0); the context's own sum buffer and result are not touched.  The call allocates
+ * nothing but it is host-synchronous: the host waits for the stream once per bounce (a 4-byte read-back of the
+ * survivor count sizes the next launches) and once more before it returns, so it must NOT be issued on a stream
+ * that is being captured into a HIP graph (the waits would fail with hipErrorStreamCaptureUnsupported and
+ * invalidate the capture).  One sample of every pixel of the image, padded to whole 64x64
  * pixel blocks, must fit: (176 + 44 x light samples per segment) bytes per padded pixel, i.e. up to
  * 384x448 pixels with two quad lights; larger images -> PTC_ERR_INVALID with a message that
  * says so.  Scene, lights and options must be set up (ptc_set_*, ptc_build) before, with the ordinary
  * calls.  With reference seeding the range must start at 0 with clear (no per-pixel history is kept
- * between calls).  All contexts of a process on one GPU share that GPU's array: calls that overlap in
- * time on one GPU race and must be serialised by the caller. */
+ * between calls).  All contexts of a process on one GPU share that GPU's array, so one call at a time may
+ * use it: a call that finds the array in use by another context or thread returns PTC_ERR_BUSY at once and has
+ * touched nothing (try again later); a call that fails part way waits for its kernels before it lets go of the
+ * array. */
 #define PTC_STATIC_SCRATCH_MIB 48
 int  ptc_render_range_static(ptc_context* ctx, int frame_id, uint32_t width, uint32_t height,
                              int32_t spp_begin, int32_t spp_end, int clear, void* sums_device, size_t sums_bytes);

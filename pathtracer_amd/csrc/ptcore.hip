@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -32,6 +33,16 @@ std::string g_create_error;
 constexpr int kMaxDevices = 64;
 unsigned char* g_scratch_ptr[kMaxDevices] = {nullptr};  // per device: address of g_static_scratch there
 std::mutex g_scratch_mutex;
+// One ptc_render_range_static call at a time per device: the array is shared by every context on that GPU, and two
+// calls that overlapped would write each other's path state.  Taken on entry, released after the call's last
+// kernel has finished.
+std::atomic<bool> g_scratch_busy[kMaxDevices];
+struct DeviceBuffer {  // a temporary device allocation that every return path releases
+    void* p = nullptr;
+    ~DeviceBuffer() {
+        if (p) (void)hipFree(p);
+    }
+};
 const char* kIntegrators[] = {"raytracer", "analyticdirect", "direct", "pathtracer", "pathtracer2"};
 }  // namespace
 
@@ -248,7 +259,12 @@ int ensurePaths(ptc_context* ctx, uint32_t capacity, uint32_t contrib_samples) {
     PathState ps{};
     uint32_t *hq = nullptr, *gq = nullptr;
     const size_t bytes = carvePaths(nullptr, capacity, contrib_samples, ps, hq, gq);
-    CHK(hipMalloc(&ctx->path_pool, bytes));  // the only allocation: nothing is left half done when it fails
+    const hipError_t e = hipMalloc(&ctx->path_pool, bytes);  // the only allocation: nothing is left half done when it fails
+    if (e != hipSuccess) {
+        ctx->path_pool = nullptr;
+        (void)hipGetLastError();
+        return fail(ctx, e == hipErrorOutOfMemory ? PTC_ERR_NOMEM : PTC_ERR_DEVICE, std::string("allocating the path arrays (") + std::to_string(bytes) + " bytes): " + hipGetErrorString(e));
+    }
     ctx->path_pool_bytes = bytes;
     carvePaths((char*)ctx->path_pool, capacity, contrib_samples, ctx->ps, ctx->hitq, ctx->gatherq);
     ctx->contrib_samples = contrib_samples;
@@ -573,7 +589,9 @@ int renderRange(ptc_context* ctx, int frame_id, uint32_t w, uint32_t h, int32_t 
     per_batch = std::min<uint64_t>(per_batch, (uint64_t)std::max(1, j1 - j0));
     per_batch = std::max<uint64_t>(1u, std::min<uint64_t>(per_batch, 0x3FFFFFF0ull / ctx->npix_pad));
     if ((uint64_t)ctx->npix_pad * per_batch > 0x3FFFFFF0ull) return fail(ctx, PTC_ERR_INVALID, "batch too large");  // path numbers keep their top two bits free (gather records)
-    rc = ensurePaths(ctx, (uint32_t)(ctx->npix_pad * per_batch), S);
+    // Several contexts on one GPU (ranks or host threads sharing it) size their batches from the same free-memory
+    // figure at the same moment: when the allocation fails for lack of memory, try again with half the batch.
+    while ((rc = ensurePaths(ctx, (uint32_t)(ctx->npix_pad * per_batch), S)) == PTC_ERR_NOMEM && per_batch > 1u) per_batch = (per_batch + 1u) / 2u;
     if (rc) return rc;
     ctx->stats.batch_paths = std::max<uint64_t>(ctx->stats.batch_paths, ctx->npix_pad * per_batch);
     ctx->stats.path_state_bytes = ctx->path_pool_bytes;
@@ -916,6 +934,9 @@ int ptc_render_range_static(ptc_context* ctx, int frame_id, uint32_t width, uint
         head + carvePaths(nullptr, (uint32_t)npix_pad, S, ps, hq, gq) > PTC_STATIC_SCRATCH_BYTES)
         return fail(ctx, PTC_ERR_INVALID, "image too large for the static scratch (" + std::to_string(PTC_STATIC_SCRATCH_MIB) + " MiB): one sample of every pixel of the image, padded to 64x64 blocks, needs " +
                                               std::to_string(bytesPerPath(S) + 8u) + " bytes per pixel with " + std::to_string(S) + " light samples per segment");
+    // one call at a time per device; released below, after this call's last kernel has finished
+    if (g_scratch_busy[ctx->device].exchange(true, std::memory_order_acquire))
+        return fail(ctx, PTC_ERR_BUSY, "the static scratch of this GPU is in use by another ptc_render_range_static call");
     // the context's own arrays step aside for the duration of the call
     struct Saved {
         PathState ps;
@@ -940,6 +961,12 @@ int ptc_render_range_static(ptc_context* ctx, int frame_id, uint32_t width, uint
         return PTC_OK;
     };
     rc = run();
+    if (rc) {  // kernels of the failed call may still be writing the scratch: wait for both streams before letting go of it
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamSynchronize(ctx->aux_stream);
+        (void)hipGetLastError();
+    }
+    g_scratch_busy[ctx->device].store(false, std::memory_order_release);
     ctx->ps = saved.ps;
     ctx->hitq = saved.hitq;
     ctx->gatherq = saved.gatherq;
@@ -1117,16 +1144,14 @@ int ptc_probe_segments(ptc_context* ctx, uint32_t n, const PtcSegmentProbe* in, 
     CHK(hipMemcpyAsync(ctx->ps.L, L.data(), n * sizeof(float4), hipMemcpyHostToDevice, s));
     CHK(hipStreamSynchronize(s));
     const DevScene sc = deviceScene(ctx);
-    void* tmp = nullptr;
-    CHK(hipMalloc(&tmp, (size_t)n * 8));
+    DeviceBuffer tmp_guard;  // freed on every return path
+    CHK(hipMalloc(&tmp_guard.p, (size_t)n * 8));
+    void* const tmp = tmp_guard.p;
     uint32_t alive_n = 0;
     const PtcStats saved = ctx->stats;
     rc = runBounces(ctx, rp, sc, n, 0u, 1u, &alive_n, false);
     ctx->stats = saved;  // probes are not part of the render statistics
-    if (rc) {
-        (void)hipFree(tmp);
-        return rc;
-    }
+    if (rc) return rc;
     // hit_t / hit_ref are indexed by the position of the segment, which is the probe number here
     wf_probe_hits(s, sc, ctx->ps, n, (int32_t*)tmp, (float*)tmp + n);
     std::vector<int32_t> prim(n);
@@ -1140,7 +1165,6 @@ int ptc_probe_segments(ptc_context* ctx, uint32_t n, const PtcSegmentProbe* in, 
         CHK(hipMemcpyAsync(t.data(), ctx->ps.thr, alive_n * sizeof(float4), hipMemcpyDeviceToHost, s));
     }
     CHK(hipStreamSynchronize(s));
-    (void)hipFree(tmp);
     CHK(hipGetLastError());
     for (uint32_t i = 0; i < n; ++i) {
         std::memset(&out[i], 0, sizeof(out[i]));

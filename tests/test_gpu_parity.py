@@ -166,7 +166,7 @@ def test_mis_nan_mask():
 
 def test_dragon_render_small():
     scene = load("scene4/dragon.test", size="160 120", spp="2")
-    compare_render(scene, semantics=1, seeding=1, use_bvh=1, min_close=0.97, max_block_rel=0.05)
+    compare_render(scene, semantics=1, seeding=1, use_bvh=1, min_close=0.99, max_block_rel=0.02)
 
 
 def test_sample_range_partition_is_exact():
@@ -288,12 +288,61 @@ def test_sphere_png_from_the_gpu():
     assert (d <= 1).mean() > 0.9999
 
 
+def test_red_dragon_png_from_the_gpu():
+    """scene 1/scene7.test at the 1280x1024 of images/red_dragon.png (`raytracer`: Blinn-Phong, one point light,
+    shadow rays, mirror recursion to maxdepth 5 over the 100 000-triangle dragon; RayTracer.cu:34-105): the GPU
+    result through Renderer::getResult against the image the reference recorded -- byte-exact on > 99.9 % of the
+    pixels (the oracle: 99.94 %), all but 0.05 % within one grey level."""
+    import os
+    from util import ROOT, dragon_variant, read_png
+    scene = SceneLoader().loadText(dragon_variant("raytracer", size="1280 1024"))
+    r = Renderer(scene, options={_ffi.OPT_SEMANTICS: 0, _ffi.OPT_SEEDING: 0})
+    r.run()
+    mine = np.frombuffer(bytes(r.getResult()), dtype=np.uint8).reshape(1024, 1280, 4)[..., :3].astype(int)
+    r.close()
+    ref = read_png(os.path.join(ROOT, "tests", "golden", "ref_red_dragon.png"))[..., :3].astype(int)
+    d = np.abs(mine - ref).max(axis=2)
+    assert (d == 0).mean() > 0.999, (d == 0).mean()
+    assert (d <= 1).mean() > 0.9995, (d <= 1).mean()
+    assert np.allclose(mine.mean(axis=(0, 1)), ref.mean(axis=(0, 1)), rtol=1e-3)
+
+
+def test_cosine_sampling_at_full_size():
+    """scene 4/cornellCosine.test as shipped (480x480 x 64 spp, `intended` semantics).  Against the oracle under
+    counter seeding: per-pixel and block bars of every other render here.  Against images/cornellBRDF.png, the only
+    recorded image of this box: the loose bars of tests/test_oracle_golden.py (the image comes from another state
+    of the code; channel means within 7 %, 16x16-pixel block means within 12 % relative RMSE -- the oracle
+    measures 5.9 % / 10.5 %)."""
+    import os
+    from util import ROOT, read_png
+    scene = SceneLoader().load(os.path.join(ROOT, "scenes", "scene4", "cornellCosine.test"))
+    assert (scene.width, scene.height, scene.samples_per_pixel, scene.sampling_method) == (480, 480, 64, 1)
+    r = Renderer(scene, options={_ffi.OPT_SEMANTICS: 1, _ffi.OPT_SEEDING: 1})
+    r.run()
+    gsum = r.sums()
+    mine = np.frombuffer(bytes(r.getResult()), dtype=np.uint8).reshape(480, 480, 4)[..., :3].astype(np.float64)
+    r.close()
+    ref = read_png(os.path.join(ROOT, "tests", "golden", "ref_cornellBRDF.png"))[..., :3].astype(np.float64)
+    bm, br = block_mean(mine, 16), block_mean(ref, 16)
+    relrmse = np.sqrt(((bm - br) ** 2).mean()) / br.mean()
+    assert relrmse < 0.12, relrmse
+    assert np.abs(mine.mean(axis=(0, 1)) / ref.mean(axis=(0, 1)) - 1).max() < 0.07
+    # every fourth pixel in x and y through the oracle, same seeds
+    S = 4
+    wsum, _, _ = orc().render(scene, semantics=1, seeding=1, stride=S, threads=8)
+    a, b = gsum[::S, ::S], wsum[::S, ::S]
+    assert close_fraction(a, b) >= 0.99, close_fraction(a, b)
+    bm_g, bm_w = block_mean(a, 8), block_mean(b, 8)
+    assert np.sqrt(((bm_g - bm_w) ** 2).mean()) / np.abs(bm_w).mean() <= 0.02
+
+
 @pytest.mark.parametrize("name,rel,tol", [("cornellRR", "scene3/cornellRR.test", 0.04), ("ggx", "scene4/ggx.test", 0.02)])
 def test_converged_images_match_the_reference(name, rel, tol):
     """Full-size renders at the scene's own settings (`intended` semantics, reference
     seeding) against the reference's images: relative RMSE of 16x16-pixel block means
-    <= tol (3.5 % / 2 %: the Monte-Carlo noise of two independent 64-spp renders), channel
-    means within 2 %."""
+    <= tol, channel means within 2 %.  The figure is the Monte-Carlo noise of two independent 64-spp renders, not a
+    bias: the oracle measures 3.69 % (reference seeding) / 3.68 % (counter seeding) on cornellRR against the same
+    image and 1.04 % / 1.32 % on ggx (tests/test_oracle_golden.py); bars = those + 0.3 points / 2 %."""
     import os
     from util import ROOT, read_png
     scene = SceneLoader().load(os.path.join(ROOT, "scenes", rel))
@@ -375,4 +424,4 @@ def test_other_dragon_scenes(kind, semantics):
     want = orc().primary_hits(scene, use_bvh=1)
     for f in ("prim", "t", "u", "v"):
         assert np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32)), f
-    compare_render(scene, semantics=semantics, seeding=1, use_bvh=1, bounce_cap=8, min_close=0.97, max_block_rel=0.05)
+    compare_render(scene, semantics=semantics, seeding=1, use_bvh=1, bounce_cap=8, min_close=0.99, max_block_rel=0.02)

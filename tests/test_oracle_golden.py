@@ -74,6 +74,54 @@ def test_sphere_png_is_reproduced():
     assert st.paths == 640 * 480 and st.shadow_rays > 75 * 100000
 
 
+
+def test_red_dragon_png_is_reproduced():
+    """images/red_dragon.png is scene 1/scene7.test (the dragon alone, one point light, the default
+    `raytracer` integrator: Blinn-Phong + mirror recursion, RayTracer.cu:34-105) rendered at 1280x1024
+    instead of the file's `size 640 480` (:3).  The oracle, `literal` semantics and reference seeding,
+    reproduces it byte for byte on 99.94 % of the pixels (99.96 % within one grey level; channel means
+    19.527 / 7.124 / 7.124 against 19.531 / 7.126 / 7.126): pins closestHit, its shadow rays and the
+    triangle program over the 100 000-triangle mesh against the reference's own output."""
+    from util import dragon_variant
+    scene = SceneLoader().loadText(dragon_variant("raytracer", size="1280 1024"))
+    assert scene.integratorName == "raytracer" and len(scene.triangles) == 100000
+    _, res, _ = orc.render(scene, threads=8, semantics=0, seeding=0, use_bvh=1)
+    mine = orc.to_rgba8(res)[..., :3].astype(int)
+    ref = read_png(os.path.join(GOLD, "ref_red_dragon.png"))[..., :3].astype(int)
+    assert mine.shape == ref.shape == (1024, 1280, 3)
+    d = np.abs(mine - ref).max(axis=2)
+    assert (d == 0).mean() > 0.999
+    assert (d <= 1).mean() > 0.9995
+    assert np.allclose(mine.mean(axis=(0, 1)), ref.mean(axis=(0, 1)), rtol=1e-3)
+
+
+def test_cornellBRDF_image_holds_cosine_sampling_only_weakly():
+    """images/cornellBRDF.png against scene 4/cornellCosine.test (cornellBRDF.test with `importancesampling
+    cosine`, the one line that differs) at the file's own 480x480 x 64 spp, `intended` semantics.  The image
+    was made by some other state of the code -- ceiling 15-30 % darker, the sphere's surroundings 20-50 %
+    brighter than any of the committed estimators -- so it holds the path only loosely.  Measured: cosine
+    sampling channel means +5.1 % / +5.9 % / +5.4 %, relative RMSE of 16x16-pixel block means 10.5 %;
+    uniform hemisphere +3.1 % / 9.6 %; BRDF sampling (the file's own mode) +10.8 % / 14.2 %.  (At 240x240 x 16
+    spp the cosine render's 8-bit means come out within 1.5 % of the image: gamma 1/2.2 of noisier pixels
+    averages lower, which hides the offset.)  Bars: means within 7 %, blocks within 12 %, and closer than
+    BRDF sampling is."""
+    ref = read_png(os.path.join(GOLD, "ref_cornellBRDF.png"))[..., :3].astype(np.float64)
+    S = 2
+    err = {}
+    for rel in ("scene4/cornellCosine.test", "scene4/cornellBRDF.test"):
+        scene = SceneLoader().load(os.path.join(ROOT, "scenes", rel))
+        assert (scene.width, scene.height, scene.samples_per_pixel) == (480, 480, 64)
+        top_rows = (scene.height - 1 - np.arange(0, scene.height, S))[::-1]
+        _, res, _ = orc.render(scene, threads=8, semantics=1, seeding=1, stride=S)
+        mine_s = orc.to_rgba8(res)[top_rows][:, ::S, :3].astype(np.float64)
+        ref_s = ref[top_rows][:, ::S]
+        bm, br = block_mean(mine_s, 8), block_mean(ref_s, 8)
+        err[rel] = (np.sqrt(((bm - br) ** 2).mean()) / br.mean(), np.abs(mine_s.mean(axis=(0, 1)) / ref_s.mean(axis=(0, 1)) - 1).max())
+    cos, brdf = err["scene4/cornellCosine.test"], err["scene4/cornellBRDF.test"]
+    assert cos[0] < 0.12 and cos[1] < 0.07, err
+    assert brdf[0] > cos[0] + 0.02 and brdf[1] > cos[1] + 0.03, err
+
+
 def _strided_blocks(img, stride, block):
     return block_mean(img[::stride, ::stride].astype(np.float64), block)
 
@@ -82,7 +130,11 @@ def _strided_blocks(img, stride, block):
 def test_intended_semantics_match_reference_images(name, rel, tol):
     """Every other pixel in x and y at the scene's own 64 spp; 8x8 blocks of those
     (16x16 pixel areas) must agree with the reference image within `tol` relative
-    RMSE.  Literal semantics are far off (next test)."""
+    RMSE.  Literal semantics are far off (next test).  Measured: cornellRR 3.69 % under reference seeding and
+    3.68 % under counter seeding (two independent noise realisations of the same estimator against the image's
+    own: the figure is the Monte-Carlo noise of 64-spp block means, not a bias -- channel means agree within
+    0.3/255); it was 3.4 % while the oracle still culled dead paths under reference seeding, which gave the pixels
+    other seeds, i.e. a third realisation.  The bar is the larger value + 0.3 points.  ggx: 1.04 % / 1.32 %, bar 2 %."""
     scene = SceneLoader().load(os.path.join(ROOT, "scenes", rel))
     _, res, _ = orc.render(scene, threads=8, semantics=1, stride=2)
     mine = orc.to_rgba8(res)[::-1][::2, ::2][::-1]  # rows were flipped by the conversion

@@ -60,3 +60,42 @@ def test_static_entry_point_rejects_what_does_not_fit():
         r.width, r.height = 64, 64
         r.render_range_static(0, 1, out.data_ptr(), 64 * 64 * 3 * 4 - 4)
     r.close()
+
+
+def test_two_contexts_from_two_threads_get_correct_sums_or_the_busy_error():
+    """All contexts on one GPU share that GPU's scratch array.  Two contexts calling from two host threads at the
+    same time: every call either returns the sums ptc_render_range gives, bit for bit, or fails with the "in use"
+    error having written nothing of its own -- never a success with another call's path state mixed in."""
+    import threading
+    import torch
+    scene = SceneLoader().loadText(override_scene_text(scene_text("scene3/cornellRR.test"), size="192 160", spp="6"))
+    opts = {_ffi.OPT_SEMANTICS: 1, _ffi.OPT_SEEDING: 1, _ffi.OPT_BOUNCE_CAP: 8}
+    rs = [Renderer(scene, options=opts) for _ in range(2)]
+    rs[0].render_range(0, 6, clear=True)
+    want = rs[0].sums()
+    outs = [torch.zeros(scene.height * scene.width * 3, dtype=torch.float32, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
+    results = [[], []]
+    start = threading.Barrier(2)
+
+    def work(k):
+        start.wait()
+        for _ in range(6):
+            try:
+                rs[k].render_range_static(0, 6, outs[k].data_ptr(), outs[k].numel() * 4, clear=True)
+                got = outs[k].cpu().numpy().reshape(scene.height, scene.width, 3)
+                results[k].append(bool(np.array_equal(got.view(np.uint32), want.view(np.uint32))))
+            except RuntimeError as e:
+                assert "in use" in str(e), e
+                results[k].append(None)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for r in rs:
+        r.close()
+    flat = results[0] + results[1]
+    assert len(flat) == 12 and False not in flat, results
+    assert flat.count(True) >= 2  # a call is only ever refused while the other context's call is running
