@@ -17,7 +17,9 @@ before anything here touches a GPU, relays rank 0's line and fails if any rank f
 ranks.
 
 Prints ONE JSON line: Mrays/s (extension segments = paths x bounces, whole job), the roofline object
-of the dominant kernel class (extension-ray traversal) and the CPU-oracle baseline.
+of the dominant kernel class (extension-ray traversal) and the CPU-oracle baseline.  The default single-GPU
+run (workload dragon) then measures the other half of the metric's config, the Cornell box with the GGX sphere
+(512x512, 4096 spp), and attaches it as "secondary" with the roofline object of ITS dominant kernel, k_surface.
 """
 import argparse
 import json
@@ -87,6 +89,8 @@ def parse_args(argv=None):
     ap.add_argument("--strong", action="store_true", help="divide the workload's samples among the ranks (default: every rank renders all of them)")
     ap.add_argument("--ordered-reduce", action="store_true", help="gather the ranks' sums and add them in rank order on rank 0 (deterministic) instead of one sum-reduce")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="do not measure the Cornell GGX workload after the dragon (default single-GPU run)")
+    ap.add_argument("--secondary-steps", type=int, default=5)
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--batch", type=int, default=None, help="PTC_OPT_BATCH_PATHS")
     ap.add_argument("--builder", type=int, default=None, help="PTC_OPT_BVH_BUILDER")
@@ -161,24 +165,210 @@ def launcher_selftest(rank, world):
 
 # -------------------------------------------------------------------------------- one rank --
 def quoted_counters(workload, semantics, overridden):
-    """Per-launch hardware-counter figures of the traversal kernels for this workload, as committed by
-    tools/pmc_summary.py from rocprofv3 --pmc passes of this same command (they cannot be collected
-    inside a normal run)."""
+    """Per-launch hardware-counter figures of this workload's kernels, as committed by tools/pmc_summary.py from
+    rocprofv3 --pmc passes of this same command (they cannot be collected inside a normal run) -> (entry, stale).
+    Every entry carries the hash of the device sources it was measured on; when the sources have changed since,
+    `stale` is true and the caller must not derive a roofline fraction from the entry."""
+    from pathtracer_amd.srchash import device_source_hash
     path = os.path.join(ROOT, "pmc_counters.json")
     if overridden or not os.path.exists(path):
-        return None
+        return None, False
     try:
         data = json.load(open(path))
     except ValueError:
-        return None
-    return data.get(f"{workload}/semantics{semantics}")
+        return None, False
+    e = data.get(f"{workload}/semantics{semantics}")
+    if e is None:
+        return None, False
+    return e, e.get("code_hash") != device_source_hash()
+
+
+def valu_roofline(e, units_per_launch, avg_launch_s, per_unit, q, stale):
+    """The VALU-issue and HBM fractions of one kernel class from its quoted counter entry `e` (per work item: ray or
+    hit) and this run's live launch size and duration."""
+    clock_ghz = e["clock_ghz"]
+    insts = e[f"valu_insts_per_{per_unit}"]
+    valu_rate = insts * units_per_launch / avg_launch_s          # wave instructions per second
+    valu_peak = CUS * SIMDS_PER_CU * clock_ghz * 1e9 / VALU_CYCLES_PER_WAVE_INST
+    hbm_bytes = e[f"hbm_bytes_per_{per_unit}"] * units_per_launch
+    out = {
+        "bound": "valu", "achieved": round(valu_rate / 1e9, 1), "peak": round(valu_peak / 1e9, 1), "unit": "G wave-instructions/s",
+        "frac": round(valu_rate / valu_peak, 4),
+        "peak_note": f"{CUS} CUs x {SIMDS_PER_CU} SIMDs x {clock_ghz:.3f} GHz (GRBM_GUI_ACTIVE / 8 / kernel time in the counter pass) / {VALU_CYCLES_PER_WAVE_INST:.0f} cycles per wave64 instruction",
+        f"valu_insts_per_{per_unit}": round(insts, 1), "active_lane_frac": round(e["active_lane_frac"], 3),
+        "salu_per_valu": round(e["salu_per_valu"], 3),
+        "traffic": round(hbm_bytes, 1),
+        "traffic_note": f"HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) per {per_unit} from the committed counter passes x this run's {per_unit}s per launch; quoted, not measured in this run",
+        "hbm_GBs": round(hbm_bytes / avg_launch_s / 1e9, 1), "hbm_peak_GBs": HBM_PEAK_GBS, "hbm_frac": round(hbm_bytes / avg_launch_s / 1e9 / HBM_PEAK_GBS, 4),
+        "counters_from": q.get("source", "pmc_counters.json"), "counters_code_hash": q.get("code_hash"), "counters_stale": False,
+    }
+    if stale:
+        # the kernels have changed since the counter passes: the per-ray figures may no longer hold
+        for k in ("achieved", "frac", "traffic", "hbm_GBs", "hbm_frac"):
+            out[k] = None
+        out["counters_stale"] = True
+        out["note"] = "the device sources differ from the ones the committed counter passes ran on (tools/pmc_passes.sh has to be run again): no fraction is derived"
+    return out
+
+
+def measure(args, workload, steps, warmup, dist, rank, world, local_rank, shared, cdev, with_cpu_baseline):
+    """Warm up, time `steps` renders of `workload` (this rank's share + the reduce) and return rank 0's result object
+    (None on the other ranks)."""
+    import torch
+    from pathtracer_amd import Renderer, _ffi
+    from pathtracer_amd.distributed import split_render_step
+    secondary = workload != args.workload
+    spp_over, size_over = (None, None) if secondary else (args.spp or None, args.size or None)
+    scene = build_scene(workload, spp_over, size_over)
+    spp_job = scene.samples_per_pixel
+    if args.strong:
+        if spp_job % world:
+            raise SystemExit(f"--strong: {spp_job} samples do not divide among {world} ranks")
+        spp = spp_job // world
+    else:
+        spp = spp_job
+    W, H = scene.width, scene.height
+
+    opts = {_ffi.OPT_SEMANTICS: args.semantics, _ffi.OPT_SEEDING: 1}
+    if not secondary:
+        if args.tune is not None:
+            opts[_ffi.OPT_TUNE_TRAVERSAL] = args.tune
+        if args.batch is not None:
+            opts[_ffi.OPT_BATCH_PATHS] = args.batch
+        if args.sort_rays is not None:
+            opts[_ffi.OPT_SORT_RAYS] = args.sort_rays
+    if args.builder is not None:
+        opts[_ffi.OPT_BVH_BUILDER] = args.builder
+    for kv in args.opt:
+        k, v = kv.split("=")
+        opts[int(k, 0)] = int(v, 0)
+    r = Renderer(scene, device=local_rank, options=opts)
+    sums = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda")
+    r.bind_sum_buffer(sums.data_ptr(), sums.numel() * 4)
+    r.set_stream(torch.cuda.current_stream().cuda_stream)
+    phase = {"render_s": 0.0, "reduce_s": 0.0}
+
+    def step():
+        # this rank's share of the global sample index space, then one RCCL reduce
+        split_render_step(r, sums, rank, world, spp, dist, ordered=args.ordered_reduce, stage_on_host=shared, phase_times=phase)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # traversal statistics for the algorithmic-bytes figure (outside the timed region)
+    r.set_option(_ffi.OPT_COUNT_TRAVERSAL, 1)
+    r.reset_stats()
+    r.render_range(0, min(spp, 2), clear=True)
+    r.synchronize()
+    st = r.stats()
+    nodes_per_ray = st.nodes_visited / max(st.extension_rays, 1)
+    prims_per_ray = st.prims_tested / max(st.extension_rays, 1)
+    snodes_per_ray = st.shadow_nodes_visited / max(st.shadow_rays, 1)
+    sprims_per_ray = st.shadow_prims_tested / max(st.shadow_rays, 1)
+    r.set_option(_ffi.OPT_COUNT_TRAVERSAL, 0)
+
+    for _ in range(warmup):
+        step()
+    sync()
+    r.set_option(_ffi.OPT_PROFILE, 1)
+    r.reset_stats()
+    phase["render_s"] = phase["reduce_s"] = 0.0
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    st = r.stats()
+    r.set_option(_ffi.OPT_PROFILE, 0)
+
+    tvals = torch.tensor([dt, phase["render_s"], phase["reduce_s"]], dtype=torch.float64, device=cdev)
+    tmin = torch.tensor([phase["render_s"]], dtype=torch.float64, device=cdev)
+    counts = torch.tensor([st.extension_rays, st.shadow_rays, st.paths], dtype=torch.float64, device=cdev)
+    if world > 1:
+        dist.all_reduce(tvals, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    dt = float(tvals[0])
+    ext_rays, shadow_rays, paths = (float(x) for x in counts)
+
+    out = None
+    if rank == 0:
+        overridden = bool(spp_over or size_over)
+        # Extension-ray traversal (k_trace_deferred<false>; k_extend_static for tiny hierarchies) is the
+        # kernel class the roofline is quoted on (rank 0's launches).  Times: HIP events on the launch
+        # stream, live.  Instruction and byte counts per ray: hardware counters of the same command,
+        # committed in pmc_counters.json (they need rocprofv3 --pmc passes of their own).
+        launches = max(int(st.extend_launches), 1)
+        extend_s = st.extend_ms * 1e-3
+        rays_per_launch = st.extension_rays / launches
+        avg_launch_s = extend_s / launches if extend_s > 0 else 0.0
+        # algorithmic bytes per extension ray: the ray (2 x float4 = 32 B) read, the hit (t + ref = 8 B) written,
+        # 4 B for the queue slot, 64 B per BVH node visited and 48 B per triangle tested -- served mostly by L1/L2
+        b_ext = 44.0 + 64.0 * nodes_per_ray + 48.0 * prims_per_ray
+        b_sh = 44.0 + 64.0 * snodes_per_ray + 48.0 * sprims_per_ray
+        on_chip_gbs = (b_ext * st.extension_rays / extend_s / 1e9) if extend_s > 0 else 0.0
+        q, stale = quoted_counters(workload, args.semantics, overridden)
+        surf_launches = max(int(st.shade_launches), 1)
+        hits_per_launch = st.surface_hits / surf_launches
+        surf_avg_s = st.surface_ms * 1e-3 / surf_launches
+        kernel_ms = {"extend": round(st.extend_ms, 2), "shadow": round(st.connect_ms, 2), "surface": round(st.surface_ms, 2), "gather": round(st.gather_ms, 2),
+                     "other": round(st.other_ms, 2)}
+        roofline = {
+            "kernel": "extension-ray traversal (k_trace_deferred<false> over four-wide nodes; k_extend_static / k_extend for hierarchies of at most 6 / 64 nodes)",
+            "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": int(st.extend_launches), "rays_per_launch": round(rays_per_launch, 1),
+            "nodes_per_ray": round(nodes_per_ray, 2), "prims_per_ray": round(prims_per_ray, 2),
+            "algorithmic_bytes_per_ray": round(b_ext, 1), "algorithmic_bytes_per_launch": round(b_ext * rays_per_launch, 1),
+            "on_chip_GBs": round(on_chip_gbs, 1),
+            "on_chip_note": "algorithmic bytes / kernel time; node and triangle records are served by L1/L2, so this is NOT a fraction of the HBM peak",
+            "kernel_ms": kernel_ms,
+            "shadow": {"algorithmic_bytes_per_ray": round(b_sh, 1), "nodes_per_ray": round(snodes_per_ray, 2), "prims_per_ray": round(sprims_per_ray, 2),
+                       "rays": int(st.shadow_rays)},
+            "surface": {"hits": int(st.surface_hits), "launches": int(st.shade_launches), "hits_per_launch": round(hits_per_launch, 1), "avg_launch_ms": round(surf_avg_s * 1e3, 4)},
+        }
+        none = {"bound": "valu", "achieved": None, "peak": None, "unit": "G wave-instructions/s", "frac": None, "traffic": None,
+                "note": "no committed counter passes for this workload / override: only event-timed figures"}
+        roofline.update(valu_roofline(q["extend"], rays_per_launch, avg_launch_s, "ray", q, stale) if q and "extend" in q and avg_launch_s > 0 else none)
+        # the surface kernel (closest-hit programs): the longest kernel of the Cornell boxes
+        surf = dict(roofline["surface"], kernel="k_surface: light samples, BRDF sampling, throughput, roulette, queues of the next bounce")
+        surf.update(valu_roofline(q["surface"], hits_per_launch, surf_avg_s, "hit", q, stale) if q and "surface" in q and surf_avg_s > 0 else none)
+        roofline["surface"] = surf
+        cpu = None
+        if with_cpu_baseline:
+            cpu = cpu_baseline(args, scene)
+        host_ms = round(st.build_host_ms, 2)
+        out = {
+            "metric": "Mrays/s (paths x bounces)", "value": round(ext_rays / dt / 1e6, 2), "unit": "Mrays/s",
+            "n_gpus": 1 if shared else world, "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "the reference's own scene file (scenes/" + WORKLOADS[workload]["scene"] + ") at the config's size and sample count; nothing synthetic, no weights",
+            "config": {"workload": WORKLOADS[workload]["name"] + (" [overridden]" if overridden else ""),
+                       "width": W, "height": H, "spp_per_gpu": spp, "spp_total": spp * world, "semantics": "intended" if args.semantics else "literal",
+                       "seeding": "counter", "parallelism": f"spp-split x{world}" + (" (rehearsal: all ranks on one GPU, gloo)" if shared else ""), "reduce": "rank-ordered gather + add" if args.ordered_reduce else "one sum-reduce to rank 0"},
+            "total_mrays_per_s": round((ext_rays + shadow_rays) / dt / 1e6, 2),
+            "shadow_mrays_per_s": round(shadow_rays / dt / 1e6, 2),
+            "bounces_per_path": round(ext_rays / max(paths, 1), 3),
+            # per step: the slowest and the fastest rank's render part and the slowest rank's reduce part (host clocks around
+            # the two halves of a step, each ended by a stream synchronise)
+            "phases_ms": {"render_max": round(float(tvals[1]) / steps * 1e3, 3), "render_min": round(float(tmin[0]) / steps * 1e3, 3),
+                          "reduce_max": round(float(tvals[2]) / steps * 1e3, 3)},
+            "batch": {"paths": int(st.batch_paths), "path_state_GB": round(st.path_state_bytes / 1e9, 2)},
+            "bvh": {"builder": 3 if args.builder is None else args.builder, "nodes": int(st.bvh_nodes), "max_depth": int(st.bvh_max_depth), "build_ms": round(st.build_ms, 2),
+                    "build_host_ms": host_ms, "built_on": "gpu" if host_ms == 0 else "gpu + host passes (build_host_ms of build_ms is host code)"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+    r.close()
+    del sums
+    torch.cuda.empty_cache()
+    return out
 
 
 def run_rank(args):
     import torch
     import torch.distributed as dist
-    from pathtracer_amd import Renderer, _ffi
-    from pathtracer_amd.distributed import split_render_step
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -209,144 +399,22 @@ def run_rank(args):
         if joined != world:
             raise SystemExit(f"{joined} of {world} ranks joined")
 
-    scene = build_scene(args.workload, args.spp or None, args.size or None)
-    spp_job = scene.samples_per_pixel
-    if args.strong:
-        if spp_job % world:
-            raise SystemExit(f"--strong: {spp_job} samples do not divide among {world} ranks")
-        spp = spp_job // world
-    else:
-        spp = spp_job
-    W, H = scene.width, scene.height
-
-    opts = {_ffi.OPT_SEMANTICS: args.semantics, _ffi.OPT_SEEDING: 1}
-    if args.tune is not None:
-        opts[_ffi.OPT_TUNE_TRAVERSAL] = args.tune
-    if args.batch is not None:
-        opts[_ffi.OPT_BATCH_PATHS] = args.batch
-    if args.builder is not None:
-        opts[_ffi.OPT_BVH_BUILDER] = args.builder
-    if args.sort_rays is not None:
-        opts[_ffi.OPT_SORT_RAYS] = args.sort_rays
-    for kv in args.opt:
-        k, v = kv.split("=")
-        opts[int(k, 0)] = int(v, 0)
-    r = Renderer(scene, device=local_rank, options=opts)
-    sums = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda")
-    r.bind_sum_buffer(sums.data_ptr(), sums.numel() * 4)
-    r.set_stream(torch.cuda.current_stream().cuda_stream)
-
-    def step():
-        # this rank's share of the global sample index space, then one RCCL reduce
-        split_render_step(r, sums, rank, world, spp, dist, ordered=args.ordered_reduce, stage_on_host=shared)
-
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    # traversal statistics for the algorithmic-bytes figure (outside the timed region)
-    r.set_option(_ffi.OPT_COUNT_TRAVERSAL, 1)
-    r.reset_stats()
-    r.render_range(0, min(spp, 2), clear=True)
-    r.synchronize()
-    st = r.stats()
-    nodes_per_ray = st.nodes_visited / max(st.extension_rays, 1)
-    prims_per_ray = st.prims_tested / max(st.extension_rays, 1)
-    snodes_per_ray = st.shadow_nodes_visited / max(st.shadow_rays, 1)
-    sprims_per_ray = st.shadow_prims_tested / max(st.shadow_rays, 1)
-    r.set_option(_ffi.OPT_COUNT_TRAVERSAL, 0)
-
-    for _ in range(args.warmup):
-        step()
-    sync()
-    r.set_option(_ffi.OPT_PROFILE, 1)
-    r.reset_stats()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    dt = time.perf_counter() - t0
-    st = r.stats()
-    r.set_option(_ffi.OPT_PROFILE, 0)
-
-    tvals = torch.tensor([dt], dtype=torch.float64, device=cdev)
-    counts = torch.tensor([st.extension_rays, st.shadow_rays, st.paths], dtype=torch.float64, device=cdev)
-    if world > 1:
-        dist.all_reduce(tvals, op=dist.ReduceOp.MAX)
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
-    dt = float(tvals[0])
-    ext_rays, shadow_rays, paths = (float(x) for x in counts)
-
+    out = measure(args, args.workload, args.steps, args.warmup, dist, rank, world, local_rank, shared, cdev,
+                  with_cpu_baseline=not args.no_cpu_baseline and world == 1)
+    # BASELINE.json quotes its metric on "Cornell-GGX + dragon": the default single-GPU run measures the other half too
+    second = None
+    if args.workload == "dragon" and world == 1 and not args.no_secondary and not (args.spp or args.size):
+        second = measure(args, "cornell_ggx", max(args.secondary_steps, 1), 1, dist, rank, world, local_rank, shared, cdev, with_cpu_baseline=False)
     if rank == 0:
-        overridden = bool(args.spp or args.size)
-        # Extension-ray traversal (k_trace_deferred<false>; k_extend_static for tiny hierarchies) is the
-        # kernel class the roofline is quoted on (rank 0's launches).  Times: HIP events on the launch
-        # stream, live.  Instruction and byte counts per ray: hardware counters of the same command,
-        # committed in pmc_counters.json (they need rocprofv3 --pmc passes of their own).
-        launches = max(int(st.extend_launches), 1)
-        extend_s = st.extend_ms * 1e-3
-        rays_per_launch = st.extension_rays / launches
-        avg_launch_s = extend_s / launches if extend_s > 0 else 0.0
-        # algorithmic bytes per extension ray: the ray (2 x float4 = 32 B) read, the hit (t + ref = 8 B) written,
-        # 4 B for the queue slot, 64 B per BVH node visited and 48 B per triangle tested -- served mostly by L1/L2
-        b_ext = 44.0 + 64.0 * nodes_per_ray + 48.0 * prims_per_ray
-        b_sh = 44.0 + 64.0 * snodes_per_ray + 48.0 * sprims_per_ray
-        on_chip_gbs = (b_ext * st.extension_rays / extend_s / 1e9) if extend_s > 0 else 0.0
-        q = quoted_counters(args.workload, args.semantics, overridden)
-        roofline = {
-            "kernel": "extension-ray traversal (k_trace_deferred<false> over four-wide nodes; k_extend_static / k_extend for hierarchies of at most 6 / 64 nodes)",
-            "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": int(st.extend_launches), "rays_per_launch": round(rays_per_launch, 1),
-            "nodes_per_ray": round(nodes_per_ray, 2), "prims_per_ray": round(prims_per_ray, 2),
-            "algorithmic_bytes_per_ray": round(b_ext, 1), "algorithmic_bytes_per_launch": round(b_ext * rays_per_launch, 1),
-            "on_chip_GBs": round(on_chip_gbs, 1),
-            "on_chip_note": "algorithmic bytes / kernel time; node and triangle records are served by L1/L2, so this is NOT a fraction of the HBM peak",
-            "kernel_ms": {"extend": round(st.extend_ms, 2), "shadow": round(st.connect_ms, 2), "surface+gather": round(st.shade_ms, 2), "other": round(st.other_ms, 2)},
-            "shadow": {"algorithmic_bytes_per_ray": round(b_sh, 1), "nodes_per_ray": round(snodes_per_ray, 2), "prims_per_ray": round(sprims_per_ray, 2),
-                       "rays": int(st.shadow_rays)},
-        }
-        if q and avg_launch_s > 0:
-            e = q["extend"]
-            clock_ghz = e["clock_ghz"]
-            valu_rate = e["valu_insts_per_ray"] * rays_per_launch / avg_launch_s          # wave instructions per second
-            valu_peak = CUS * SIMDS_PER_CU * clock_ghz * 1e9 / VALU_CYCLES_PER_WAVE_INST
-            hbm_bytes = e["hbm_bytes_per_ray"] * rays_per_launch
-            roofline.update({
-                "bound": "valu", "achieved": round(valu_rate / 1e9, 1), "peak": round(valu_peak / 1e9, 1), "unit": "G wave-instructions/s",
-                "frac": round(valu_rate / valu_peak, 4),
-                "peak_note": f"{CUS} CUs x {SIMDS_PER_CU} SIMDs x {clock_ghz:.3f} GHz (GRBM_GUI_ACTIVE / 8 / kernel time in the counter pass) / {VALU_CYCLES_PER_WAVE_INST:.0f} cycles per wave64 instruction",
-                "valu_insts_per_ray": round(e["valu_insts_per_ray"], 1), "active_lane_frac": round(e["active_lane_frac"], 3),
-                "salu_per_valu": round(e["salu_per_valu"], 3),
-                "traffic": round(hbm_bytes, 1),
-                "traffic_note": "HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) per ray from the committed counter passes x this run's rays per launch; quoted, not measured in this run",
-                "hbm_GBs": round(hbm_bytes / avg_launch_s / 1e9, 1), "hbm_peak_GBs": HBM_PEAK_GBS, "hbm_frac": round(hbm_bytes / avg_launch_s / 1e9 / HBM_PEAK_GBS, 4),
-                "counters_from": q.get("source", "pmc_counters.json"),
-            })
-        else:
-            roofline.update({"bound": "valu", "achieved": None, "peak": None, "unit": "G wave-instructions/s", "frac": None, "traffic": None,
-                             "note": "no committed counter passes for this workload / override: only event-timed figures"})
-        cpu = None
-        if not args.no_cpu_baseline and world == 1:
-            cpu = cpu_baseline(args, scene)
-        out = {
-            "metric": "Mrays/s (paths x bounces)", "value": round(ext_rays / dt / 1e6, 2), "unit": "Mrays/s",
-            "n_gpus": 1 if shared else joined, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "the reference's own scene file (scenes/" + WORKLOADS[args.workload]["scene"] + ") at the config's size and sample count; nothing synthetic, no weights",
-            "config": {"workload": WORKLOADS[args.workload]["name"] + (" [overridden]" if overridden else ""),
-                       "width": W, "height": H, "spp_per_gpu": spp, "spp_total": spp * world, "semantics": "intended" if args.semantics else "literal",
-                       "seeding": "counter", "parallelism": f"spp-split x{world}" + (" (rehearsal: all ranks on one GPU, gloo)" if shared else ""), "reduce": "rank-ordered gather + add" if args.ordered_reduce else "one sum-reduce to rank 0"},
-            "total_mrays_per_s": round((ext_rays + shadow_rays) / dt / 1e6, 2),
-            "shadow_mrays_per_s": round(shadow_rays / dt / 1e6, 2),
-            "bounces_per_path": round(ext_rays / max(paths, 1), 3),
-            "batch": {"paths": int(st.batch_paths), "path_state_GB": round(st.path_state_bytes / 1e9, 2)},
-            "bvh": {"builder": 3 if args.builder is None else args.builder, "nodes": int(st.bvh_nodes), "max_depth": int(st.bvh_max_depth), "build_ms": round(st.build_ms, 2)},
-            "roofline": roofline, "cpu_baseline": cpu,
-        }
+        if not shared:
+            out["n_gpus"] = joined
+        if second is not None:
+            out["secondary"] = {"workload": second["config"]["workload"], "value": second["value"], "unit": second["unit"], "ms_per_step": second["ms_per_step"],
+                                "steps": second["steps"], "warmup": second["warmup"], "total_mrays_per_s": second["total_mrays_per_s"],
+                                "bounces_per_path": second["bounces_per_path"], "config": second["config"], "batch": second["batch"], "bvh": second["bvh"],
+                                "roofline": dict(second["roofline"]["surface"], extend=dict((k, v) for k, v in second["roofline"].items() if k not in ("surface", "shadow")),
+                                                 kernel_ms=second["roofline"]["kernel_ms"])}
         print(json.dumps(out), flush=True)
-    r.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

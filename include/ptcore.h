@@ -112,6 +112,9 @@ typedef struct PtcStats {
     double   build_ms;
     uint64_t path_state_bytes; /* device memory of the per-path arrays of a batch    */
     uint64_t batch_paths;      /* camera paths of the largest batch rendered so far  */
+    double   surface_ms, gather_ms; /* the two parts of shade_ms (PTC_OPT_PROFILE)   */
+    uint64_t surface_hits;     /* segments that hit something = work items of the surface kernel */
+    double   build_host_ms;    /* part of build_ms spent in host code (wall clock): 0 = the hierarchy was built on the GPU */
 } PtcStats;
 
 typedef struct ptc_context ptc_context;
@@ -358,6 +361,7 @@ static_assert(sizeof(PtcPointLight) == 36 && sizeof(PtcDirectionalLight) == 24, 
 static_assert(sizeof(PtcConfig) == 88 && offsetof(PtcConfig, hSize) == 48 &&
               offsetof(PtcConfig, gamma) == 64 && offsetof(PtcConfig, russian_roul) == 80, "Config is 88 bytes");
 static_assert(sizeof(PtcHitRecord) == 16, "HitRecord");
+static_assert(sizeof(PtcStats) == 176 && offsetof(PtcStats, build_host_ms) == 168, "PtcStats is 176 bytes");
 #endif
 
 #endif /* PTCORE_H */

@@ -21,6 +21,7 @@
 #include <cmath>
 #include <cstring>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <exception>
 #include <mutex>
@@ -382,6 +383,14 @@ void classify(const std::vector<Box6>& boxes, std::vector<uint32_t>& small, std:
     for (uint32_t i = 0; i < n; ++i) (isBig[i] ? big : small).push_back(i);
 }
 
+// Adds the wall-clock time of a host-side pass to a total (BvhBuildOutput::host_ms).
+struct HostPass {
+    double& total;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit HostPass(double& t) : total(t) {}
+    ~HostPass() { total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
 struct KindResult {
     std::vector<int32_t> slot_prim;  // slot -> primitive index within its kind
     uint32_t n_small = 0, n_big = 0;
@@ -389,6 +398,7 @@ struct KindResult {
     bool has_tree = false;
     Box6 tree_box, small_box, big_box;
     uint32_t max_depth = 0;
+    double host_ms = 0.0;
 };
 
 template <class T>
@@ -817,10 +827,13 @@ std::string buildKind(hipStream_t s, const Box6* d_boxes, const std::vector<Box6
             std::vector<Box6> h_box;
             std::vector<BvhNode> h_nodes;
             int root = 0;
-            sahBuild(boxes, small, pad, h_left, h_right, h_box, root);
-            rotateTree(h_left, h_right, h_box, n, root, BVH_ROTATE_PASSES);
             uint32_t depth = 0;
-            emitTree(h_left, h_right, h_box, n, root, kind, node_base, h_nodes, order, depth);
+            {
+                HostPass hp(res.host_ms);
+                sahBuild(boxes, small, pad, h_left, h_right, h_box, root);
+                rotateTree(h_left, h_right, h_box, n, root, BVH_ROTATE_PASSES);
+                emitTree(h_left, h_right, h_box, n, root, kind, node_base, h_nodes, order, depth);
+            }
             HIPCHK(hipMemcpyAsync(d_nodes + node_base, h_nodes.data(), sizeof(BvhNode) * h_nodes.size(), hipMemcpyHostToDevice, s));
             HIPCHK(hipStreamSynchronize(s));
             res.max_depth = depth;
@@ -861,9 +874,12 @@ std::string buildKind(hipStream_t s, const Box6* d_boxes, const std::vector<Box6
             int root = 0;
             std::string err = plocBuild(s, d_boxes, vals_out.p, n, pad, h_left, h_right, h_box, root);
             if (!err.empty()) return err;
-            rotateTree(h_left, h_right, h_box, n, root, BVH_ROTATE_PASSES);
             uint32_t depth = 0;
-            emitTree(h_left, h_right, h_box, n, root, kind, node_base, h_nodes, order, depth);
+            {
+                HostPass hp(res.host_ms);
+                rotateTree(h_left, h_right, h_box, n, root, BVH_ROTATE_PASSES);
+                emitTree(h_left, h_right, h_box, n, root, kind, node_base, h_nodes, order, depth);
+            }
             std::vector<uint32_t> h_sorted(n);
             HIPCHK(hipMemcpyAsync(h_sorted.data(), vals_out.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, s));
             HIPCHK(hipMemcpyAsync(d_nodes + node_base, h_nodes.data(), sizeof(BvhNode) * h_nodes.size(), hipMemcpyHostToDevice, s));
@@ -1106,6 +1122,7 @@ std::string bvh_build(hipStream_t s, const BvhBuildInput& in, BvhBuildOutput& ou
     if (!err.empty()) return err;
     out.n_nodes = TOP_NODES + kt.n_tree_nodes + ks.n_tree_nodes;
     out.max_depth = std::max(kt.max_depth, ks.max_depth) + 2u;
+    out.host_ms += kt.host_ms + ks.host_ms;
     {
         Box6 sb = emptyBox();
         for (const KindResult* k : {&kt, &ks}) {
@@ -1211,7 +1228,12 @@ std::string bvh_build(hipStream_t s, const BvhBuildInput& in, BvhBuildOutput& ou
         HIPCHK(hipStreamSynchronize(s));
         std::vector<WideNode> h_wide;
         uint32_t wdepth = 0;
-        if (collapseWide(h_bin, h_wide, wdepth, MAKE_LEAF(REF_TRI, T, 1u))) {  // slot T: the degenerate triangle after the scene's
+        bool wide_ok;
+        {
+            HostPass hp(out.host_ms);
+            wide_ok = collapseWide(h_bin, h_wide, wdepth, MAKE_LEAF(REF_TRI, T, 1u));
+        }
+        if (wide_ok) {  // slot T: the degenerate triangle after the scene's
             HIPCHK(hipMalloc((void**)&out.wnodes, h_wide.size() * sizeof(WideNode)));
             HIPCHK(hipMemcpyAsync(out.wnodes, h_wide.data(), h_wide.size() * sizeof(WideNode), hipMemcpyHostToDevice, s));
             HIPCHK(hipStreamSynchronize(s));

@@ -316,8 +316,10 @@ void collectSpans(ptc_context* c) {  // stream must be idle
     for (auto& sp : c->spans) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
-            double* dst = sp.kind == 0 ? &c->stats.extend_ms : sp.kind == 1 ? &c->stats.connect_ms : sp.kind == 2 ? &c->stats.shade_ms : &c->stats.other_ms;
+            double* dst = sp.kind == 0 ? &c->stats.extend_ms : sp.kind == 1 ? &c->stats.connect_ms : (sp.kind == 2 || sp.kind == 4) ? &c->stats.shade_ms : &c->stats.other_ms;
             *dst += ms;
+            if (sp.kind == 2) c->stats.surface_ms += ms;
+            if (sp.kind == 4) c->stats.gather_ms += ms;
         }
     }
     c->spans.clear();
@@ -491,22 +493,23 @@ int runBounces(ptc_context* ctx, const RenderParams& rp_frame, const DevScene& s
                 CHK(hipEventRecord(ctx->ev_shadow, ctx->stream));
                 CHK(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_shadow, 0));
                 {
-                    Timed t(ctx, 2, ctx->aux_stream);
+                    Timed t(ctx, 4, ctx->aux_stream);
                     wf_gather(ctx->aux_stream, rp, sc, ctx->ps, ctx->gatherq, grp + 5, count);
                 }
                 CHK(hipEventRecord(ctx->ev_gather, ctx->aux_stream));
                 gather_pending = true;
             } else {
-                Timed t(ctx, 2);
+                Timed t(ctx, 4);
                 wf_gather(ctx->stream, rp, sc, ctx->ps, ctx->gatherq, grp + 5, count);
             }
             ctx->stats.connect_launches++;
         }
         ctx->stats.shade_launches++;
-        CHK(hipMemcpyAsync(ctx->h_count, grp + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        CHK(hipMemcpyAsync(ctx->h_count, grp, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));  // {hits, survivors}
         CHK(hipStreamSynchronize(ctx->stream));
         CHK(hipGetLastError());
-        count = *ctx->h_count;
+        ctx->stats.surface_hits += ctx->h_count[0];
+        count = ctx->h_count[1];
         // the survivors' packed state becomes the current one
         std::swap(ctx->ps.o_seed, ctx->ps.o_seed_next);
         std::swap(ctx->ps.d_depth, ctx->ps.d_depth_next);
@@ -665,7 +668,7 @@ int ptc_create(int device_ordinal, ptc_context** out) try {
     if ((e = hipMalloc((void**)&ctx->qcount, N_QCOUNT * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void**)&ctx->counters, N_COUNTERS * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMemset(ctx->counters, 0, N_COUNTERS * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
-    if ((e = hipHostMalloc((void**)&ctx->h_count, sizeof(uint32_t))) != hipSuccess) return bail("hipHostMalloc", e);
+    if ((e = hipHostMalloc((void**)&ctx->h_count, 2 * sizeof(uint32_t))) != hipSuccess) return bail("hipHostMalloc", e);
     ctx->resident_waves = wf_resident_waves(device_ordinal);
     if (device_ordinal < kMaxDevices) {  // once per device, with that device current
         std::lock_guard<std::mutex> lock(g_scratch_mutex);
@@ -886,6 +889,7 @@ int ptc_build(ptc_context* ctx) try {
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, e0, e1);
     ctx->stats.build_ms = ms;
+    ctx->stats.build_host_ms = ctx->bvh.host_ms + ctx->bvh_any.host_ms;
     ctx->stats.bvh_nodes = ctx->bvh.n_nodes;
     ctx->stats.bvh_max_depth = ctx->bvh.max_depth;
     ctx->built = true;
@@ -1308,13 +1312,14 @@ int ptc_reset_stats(ptc_context* ctx) try {
     CHK(hipStreamSynchronize(ctx->stream));
     collectSpans(ctx);
     CHK(hipMemset(ctx->counters, 0, N_COUNTERS * sizeof(unsigned long long)));
-    const double build_ms = ctx->stats.build_ms;
+    const double build_ms = ctx->stats.build_ms, build_host_ms = ctx->stats.build_host_ms;
     const uint32_t nodes = ctx->stats.bvh_nodes, depth = ctx->stats.bvh_max_depth;
     const uint64_t pool = ctx->stats.path_state_bytes, bpaths = ctx->stats.batch_paths;
     ctx->stats = PtcStats{};
     ctx->stats.path_state_bytes = pool;
     ctx->stats.batch_paths = bpaths;
     ctx->stats.build_ms = build_ms;
+    ctx->stats.build_host_ms = build_host_ms;
     ctx->stats.bvh_nodes = nodes;
     ctx->stats.bvh_max_depth = depth;
     return PTC_OK;

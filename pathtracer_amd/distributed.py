@@ -38,15 +38,24 @@ def ordered_reduce(sums, rank: int, world: int, dist):
 
 
 def split_render_step(renderer, sums, rank: int, world: int, spp_per_rank: int, dist=None, ordered: bool = False,
-                      stage_on_host: bool = False):
+                      stage_on_host: bool = False, phase_times: dict = None):
     """One whole-job render.  `renderer` accumulates into `sums` (a tensor it was
     bound to, rendering on the stream torch uses -- Renderer.set_stream -- so that the
     collective is ordered after the render); `dist` is torch.distributed (needed when
     world > 1).  `stage_on_host`: the combine runs on host copies of the sums, for
     process groups that cannot move device memory (gloo) -- which is how several ranks
-    that share ONE GPU rehearse the whole path (RCCL refuses a device that appears twice)."""
+    that share ONE GPU rehearse the whole path (RCCL refuses a device that appears twice).
+    `phase_times` (a dict with "render_s" and "reduce_s"): this rank's host time in the two halves of the step is
+    added to it -- the render half ends with a stream synchronise (the render call has waited for all but its last
+    few kernels anyway), the other half (combine + resolve) with a synchronise of the device."""
+    import time
     j0, j1 = sample_range(rank, world, spp_per_rank)
+    t0 = time.perf_counter()
     renderer.render_range(j0, j1, clear=True)
+    if phase_times is not None:
+        renderer.synchronize()
+        t1 = time.perf_counter()
+        phase_times["render_s"] += t1 - t0
     if world > 1:
         buf = sums.cpu() if stage_on_host else sums  # .cpu() waits for the render on torch's stream
         if ordered:
@@ -57,3 +66,9 @@ def split_render_step(renderer, sums, rank: int, world: int, spp_per_rank: int, 
             sums.copy_(buf)
     if rank == 0:
         renderer.resolve(world * spp_per_rank)
+    if phase_times is not None:
+        renderer.synchronize()
+        if world > 1 and not stage_on_host:
+            import torch
+            torch.cuda.synchronize()  # the collective may run on a stream of its own
+        phase_times["reduce_s"] += time.perf_counter() - t1

@@ -9,7 +9,7 @@ cd /tmp
 rocprofv3 -L > "$out/avail.txt" 2>&1
 grep -io "SQC_ICACHE[A-Z_]*\|SQ_IFETCH[A-Z_]*\|SQ_INSTS_BRANCH\|SQ_WAIT_INST_ANY" "$out/avail.txt" | sort -u | tr '\n' ' ' > "$out/names.txt"
 echo "available: $(cat $out/names.txt)"
-timeout -s KILL 300 rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d "$out/pass" -- python3 $root/bench.py --no-cpu-baseline --steps 1 --warmup 0 "$@" > "$out/pass.log" 2>&1 || { echo "pass failed"; tail -5 "$out/pass.log"; exit 1; }
+timeout -s KILL 300 rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d "$out/pass" -- python3 $root/bench.py --no-cpu-baseline --no-secondary --steps 1 --warmup 0 "$@" > "$out/pass.log" 2>&1 || { echo "pass failed"; tail -5 "$out/pass.log"; exit 1; }
 python3 - "$out" <<'PY'
 import csv, glob, sys, collections
 out = sys.argv[1]

@@ -16,6 +16,9 @@ import json
 import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pathtracer_amd.srchash import device_source_hash  # noqa: E402
+
 
 def counting_variant(name):
     """k_trace_deferred<ANY, COUNT, WIDE>: second argument; the other traversal kernels: <COUNT> or <COUNT, ...>."""
@@ -66,16 +69,21 @@ def main():
     if line is None:
         raise SystemExit("no bench line in the pass logs")
     rl = line["roofline"]
-    rays = {"extend": rl["rays_per_launch"] * rl["launches"], "shadow": rl["shadow"]["rays"]}
-    entry = {"workload": line["config"]["workload"], "semantics": int(semantics), "source": source,
+    rays = {"extend": rl["rays_per_launch"] * rl["launches"], "shadow": rl["shadow"]["rays"], "surface": rl.get("surface", {}).get("hits", 0)}
+    unit = {"extend": "ray", "shadow": "ray", "surface": "hit"}
+    # the counters belong to the kernels of THIS tree: bench.py compares the hash with the sources it runs on
+    entry = {"workload": line["config"]["workload"], "semantics": int(semantics), "source": source, "code_hash": device_source_hash(),
              "how": "rocprofv3 --pmc, one pass per counter group (tools/pmc_passes.sh), bench.py --steps 1 --warmup 0; FETCH_SIZE doubled (gfx950, 16-B-per-lane reads); "
                     "clock = GRBM_GUI_ACTIVE / 8 / kernel time of the counter pass"}
     md = [f"# {source}: {line['config']['workload']} ({line['config']['semantics']})", "",
           "Sums over the dispatches of the timed step (`bench.py --steps 1 --warmup 0`), counting instantiations excluded.", ""]
-    for key in ("extend", "shadow"):
+    if "k_surface" in tot:
+        tot["surface"], disp["surface"] = tot["k_surface"], disp["k_surface"]
+    for key in ("extend", "shadow", "surface"):
         t = tot.get(key)
-        if not t or "SQ_INSTS_VALU" not in t:
+        if not t or "SQ_INSTS_VALU" not in t or not rays[key]:
             continue
+        u = unit[key]
         n = len(disp[key]["SQ_INSTS_VALU"])
         spans = [v for v in disp[key]["GRBM_GUI_ACTIVE"].values() if v]
         ksec = sum(b - a for a, b in spans) * 1e-9 if spans else None
@@ -83,18 +91,18 @@ def main():
         fetch = t.get("FETCH_SIZE", 0.0) * 1024.0 * 2.0
         write = t.get("WRITE_SIZE", 0.0) * 1024.0
         e = {"launches": n, "rays": rays[key],
-             "valu_insts_per_ray": t["SQ_INSTS_VALU"] / rays[key],
+             f"valu_insts_per_{u}": t["SQ_INSTS_VALU"] / rays[key],
              "salu_per_valu": t["SQ_INSTS_SALU"] / t["SQ_INSTS_VALU"],
              "active_lane_frac": t["SQ_THREAD_CYCLES_VALU"] / (64.0 * t["SQ_ACTIVE_INST_VALU"]),
-             "hbm_bytes_per_ray": (fetch + write) / rays[key], "fetch_bytes_per_launch": fetch / max(n, 1), "write_bytes_per_launch": write / max(n, 1),
+             f"hbm_bytes_per_{u}": (fetch + write) / rays[key], "fetch_bytes_per_launch": fetch / max(n, 1), "write_bytes_per_launch": write / max(n, 1),
              "clock_ghz": clock, "kernel_ms_in_counter_pass": ksec * 1e3 if ksec else None,
              "valu_insts_per_launch": t["SQ_INSTS_VALU"] / max(n, 1)}
         entry[key] = e
-        md += [f"## {key} traversal ({n} launches, {rays[key]:.4g} rays)"]
+        md += [f"## {key} {'traversal' if u == 'ray' else 'kernel'} ({n} launches, {rays[key]:.4g} {u}s)"]
         for c in sorted(t):
             md.append(f"- {c}: {t[c]:.6g}")
-        md += ["", f"- VALU wave instructions per ray: {e['valu_insts_per_ray']:.1f}; SALU per VALU: {e['salu_per_valu']:.3f}; active lanes: {e['active_lane_frac']:.3f}",
-               f"- HBM bytes per ray (2 x FETCH_SIZE + WRITE_SIZE): {e['hbm_bytes_per_ray']:.1f}; per launch: fetch {e['fetch_bytes_per_launch']:.4g}, write {e['write_bytes_per_launch']:.4g}"]
+        md += ["", f"- VALU wave instructions per {u}: {e[f'valu_insts_per_{u}']:.1f}; SALU per VALU: {e['salu_per_valu']:.3f}; active lanes: {e['active_lane_frac']:.3f}",
+               f"- HBM bytes per {u} (2 x FETCH_SIZE + WRITE_SIZE): {e[f'hbm_bytes_per_{u}']:.1f}; per launch: fetch {e['fetch_bytes_per_launch']:.4g}, write {e['write_bytes_per_launch']:.4g}"]
         if clock:
             rate = t["SQ_INSTS_VALU"] / ksec
             peak = 256 * 4 * clock * 1e9 / 2.0
@@ -102,7 +110,7 @@ def main():
                    f"- HBM rate in the counter pass: {(fetch+write)/ksec/1e9:.0f} GB/s = {(fetch+write)/ksec/8e12:.3f} of 8 TB/s"]
         md.append("")
     for key in sorted(tot):
-        if key in ("extend", "shadow"):
+        if key in ("extend", "shadow", "surface"):
             continue
         t = tot[key]
         md += [f"## {key}"] + [f"- {c}: {t[c]:.6g} ({len(disp[key][c])} dispatches)" for c in sorted(t)] + [""]

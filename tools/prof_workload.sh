@@ -6,7 +6,7 @@ root=$PWD
 mkdir -p $root/gpurun_out/prof
 cd /tmp
 rm -rf $root/gpurun_out/prof/$tag
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/prof/$tag -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $root/gpurun_out/prof/$tag.log 2>&1 || { echo failed; tail -5 $root/gpurun_out/prof/$tag.log; exit 1; }
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/prof/$tag -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary "$@" > $root/gpurun_out/prof/$tag.log 2>&1 || { echo failed; tail -5 $root/gpurun_out/prof/$tag.log; exit 1; }
 cd $root
 python3 tools/summarize_prof.py gpurun_out/prof/$tag gpurun_out/prof/$tag.md "$tag: bench.py --steps 2 --warmup 1 $*"
 rm -rf gpurun_out/prof/$tag

@@ -13,7 +13,7 @@ rm -rf $o/prof
 export TMPDIR=/tmp
 root=$PWD
 cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $root/$o/prof -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $root/$o/prof.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $root/$o/prof -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > $root/$o/prof.log 2>&1
 cd $root
 python3 tools/summarize_prof.py $o/prof $o/kernel_stats.md "$tag: bench.py --steps 2 --warmup 1 (dragon 1080p x 256 spp), rocprofv3 --kernel-trace --stats"
 rm -rf $o/prof

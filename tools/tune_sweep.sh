@@ -8,5 +8,5 @@ for a in "$@"; do
   t=${a%@*}; v=""; [[ "$a" == *@* ]] && v=${a#*@}
   echo "tune $a" >> $out
   if [ -n "$v" ]; then export PTCORE_LIB=$PWD/pathtracer_amd/_lib/variants/libptcore_$v.so; else unset PTCORE_LIB; fi
-  timeout -k 10 200 python bench.py --workload ${WORKLOAD:-dragon} --steps 2 --warmup 1 --no-cpu-baseline --tune $t 2>/dev/null >> $out || exit 1
+  timeout -k 10 200 python bench.py --workload ${WORKLOAD:-dragon} --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --tune $t 2>/dev/null >> $out || exit 1
 done
