@@ -182,16 +182,17 @@ enum {
      * bits 16..31 queue entries a wave reserves per atomic (multiple of 64, 0 = auto).
      * Default 0x5518. */
     PTC_OPT_TUNE_TRAVERSAL = 9,
-    /* Hierarchy builder used by the next ptc_build: 0 = LBVH (Karras radix tree over
-     * Morton codes), 1 = PLOC (locally-ordered clustering, better trees),
-     * 2 = top-down surface-area-heuristic sweep on the host (single-threaded, ten times
-     * the build time; 6 % fewer node visits for extension rays, 11 % more for shadow
-     * rays than PLOC on the dragon: +1.4 % throughput), 3 (default) = two hierarchies, the
-     * sweep's for the closest-hit rays and PLOC's for the any-hit rays (both build times,
-     * both memory footprints, +2.4 % on the dragon; same images; scenes of more than 2^19
-     * primitives get 1, the sweep is a host job).  Scenes of at most 1024
-     * primitives of a kind always get 2, and no "large primitive" leaf: in a Cornell box
-     * every wall is as large as the scene. */
+    /* Hierarchy builder used by the next ptc_build (the reference's is the device builder "Trbvh",
+     * Renderer.cpp:203-213).  0 = LBVH (Karras radix tree over Morton codes), 1 = PLOC (locally-ordered
+     * clustering over Morton order), 4 = top-down surface-area sweep (every node split where the sweep over
+     * its primitives sorted by centroid, best of the three axes, is cheapest), all nodes of a level at once
+     * with segmented scans -- each followed by tree rotations, leaf collapse, node emission and the collapse
+     * into four-wide nodes, all on the GPU; 2 = the same sweep in host code (the reference implementation
+     * the GPU sweep is tested against; ten times the build time); 3 (default) = two hierarchies, the
+     * sweep's (4) for the closest-hit rays and PLOC's for the any-hit rays (both build times, both memory
+     * footprints; same images; scenes of more than 2^19 primitives get 1).  Scenes of at most 1024
+     * primitives of a kind always get 2 (a handful of nodes: host code is quicker than the launches), and
+     * no "large primitive" leaf: in a Cornell box every wall is as large as the scene. */
     PTC_OPT_BVH_BUILDER = 10,
     /* 1 (default) = when a scene mixes shading classes (triangle / sphere hits, Phong / GGX
      * materials) the hits of a bounce are grouped by class before the surface kernel runs,

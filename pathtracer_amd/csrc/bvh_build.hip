@@ -31,6 +31,7 @@
 
 #include <rocprim/rocprim.hpp>
 
+#include "bvh_device.h"
 #include "wavefront.h"
 
 #define BB 256
@@ -41,10 +42,6 @@
     } while (0)
 
 namespace {
-
-struct Box6 {
-    float lo[3], hi[3];
-};
 
 __global__ void k_bounds_tri(const PtcTriangle* __restrict__ tris, uint32_t n, Box6* __restrict__ out) {
     const uint32_t i = blockIdx.x * BB + threadIdx.x;
@@ -489,17 +486,21 @@ void emitTree(const std::vector<int>& left, const std::vector<int>& right, const
     }
 }
 
-// PLOC over the n Morton-sorted primitives; returns the tree on the host.
-std::string plocBuild(hipStream_t s, const Box6* d_boxes, const uint32_t* d_sorted, int n, float pad, std::vector<int>& left, std::vector<int>& right,
-                      std::vector<Box6>& box, int& root) {
+// PLOC over the n Morton-sorted primitives; the tree stays on the device: d_left / d_right [n-1], node_box [2n-1], d_root [1].
+std::string plocBuild(hipStream_t s, const Box6* d_boxes, const uint32_t* d_sorted, int n, float pad, int* d_left, int* d_right, Box6* node_box_out, int* d_root) {
 #ifndef PLOC_RADIUS
 #define PLOC_RADIUS 50
 #endif
     const int radius = PLOC_RADIUS;
-    DevBuf<Box6> node_box;
-    DevBuf<int> cl_a, cl_b, cl_out, nn, valid, pos, d_left, d_right, node_count;
-    HIPCHK(node_box.alloc(2 * (size_t)n)); HIPCHK(cl_a.alloc(n)); HIPCHK(cl_b.alloc(n)); HIPCHK(cl_out.alloc(n));
-    HIPCHK(nn.alloc(n)); HIPCHK(valid.alloc(n)); HIPCHK(pos.alloc(n)); HIPCHK(d_left.alloc(n)); HIPCHK(d_right.alloc(n)); HIPCHK(node_count.alloc(1));
+    struct {
+        Box6* p;
+    } node_box{node_box_out};
+    struct {
+        int* p;
+    } d_left_{d_left}, d_right_{d_right};
+    DevBuf<int> cl_a, cl_b, cl_out, nn, valid, pos, node_count;
+    HIPCHK(cl_a.alloc(n)); HIPCHK(cl_b.alloc(n)); HIPCHK(cl_out.alloc(n));
+    HIPCHK(nn.alloc(n)); HIPCHK(valid.alloc(n)); HIPCHK(pos.alloc(n)); HIPCHK(node_count.alloc(1));
     HIPCHK(hipMemsetAsync(node_count.p, 0, sizeof(int), s));
     hipLaunchKernelGGL(k_ploc_init, dim3(nblocks(n)), dim3(BB), 0, s, d_boxes, d_sorted, n, pad, node_box.p, cl_a.p);
     size_t temp_bytes = 0;
@@ -512,7 +513,7 @@ std::string plocBuild(hipStream_t s, const Box6* d_boxes, const uint32_t* d_sort
     for (int iter = 0; m > 1; ++iter) {
         if (iter > 4 * n + 64) return "BVH build: clustering does not converge";
         hipLaunchKernelGGL(k_ploc_nn, dim3(nblocks(m)), dim3(BB), 0, s, cur, m, node_box.p, radius, nn.p);
-        hipLaunchKernelGGL(k_ploc_merge, dim3(nblocks(m)), dim3(BB), 0, s, cur, nn.p, m, n, node_box.p, d_left.p, d_right.p, node_count.p, cl_out.p, valid.p);
+        hipLaunchKernelGGL(k_ploc_merge, dim3(nblocks(m)), dim3(BB), 0, s, cur, nn.p, m, n, node_box.p, d_left_.p, d_right_.p, node_count.p, cl_out.p, valid.p);
         size_t tb = temp_bytes;
         HIPCHK(rocprim::exclusive_scan(temp.p, tb, valid.p, pos.p, 0, (size_t)m, rocprim::plus<int>(), s));
         hipLaunchKernelGGL(k_ploc_scatter, dim3(nblocks(m)), dim3(BB), 0, s, cl_out.p, valid.p, pos.p, m, nxt);
@@ -525,15 +526,9 @@ std::string plocBuild(hipStream_t s, const Box6* d_boxes, const uint32_t* d_sort
         m = m2;
         std::swap(cur, nxt);
     }
-    left.resize(n - 1);
-    right.resize(n - 1);
-    box.resize(2 * (size_t)n - 1);
     int h_count = 0;
     HIPCHK(hipMemcpyAsync(&h_count, node_count.p, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(&root, cur, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(left.data(), d_left.p, sizeof(int) * (n - 1), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(right.data(), d_right.p, sizeof(int) * (n - 1), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(box.data(), node_box.p, sizeof(Box6) * (2 * (size_t)n - 1), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(d_root, cur, sizeof(int), hipMemcpyDeviceToDevice, s));  // the one cluster left
     HIPCHK(hipStreamSynchronize(s));
     if (h_count != n - 1) return "BVH build: clustering produced a wrong node count";
     return "";
@@ -822,6 +817,33 @@ std::string buildKind(hipStream_t s, const Box6* d_boxes, const std::vector<Box6
             for (int k = 0; k < 3; ++k) c.lo[k] = c.hi[k] = 0.5f * (boxes[i].lo[k] + boxes[i].hi[k]);
             grow(cb, c);
         }
+        DevBuf<uint32_t> ids;
+        HIPCHK(ids.alloc(n));
+        HIPCHK(hipMemcpyAsync(ids.p, small.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
+        if (builder == 4) {
+            // Surface-area sweep, rotations, leaf collapse and node emission on the device; the host sees the
+            // primitive order of the finished tree and four words about it.
+            DeviceArena arena;
+            sweep_reserve(arena, n);
+            tree_reserve(arena, n);
+            arena.reserve<int32_t>((size_t)n);
+            HIPCHK(arena.commit());
+            DeviceTree tree;
+            std::string err = sweep_build(s, arena, d_boxes, ids.p, n, pad, tree);
+            if (!err.empty()) return err;
+            err = tree_rotate(s, arena, tree, BVH_ROTATE_PASSES);
+            if (!err.empty()) return err;
+            int32_t* d_slot = arena.take<int32_t>((size_t)n);
+            if (!d_slot) return "BVH build: work space exhausted";
+            err = tree_emit(s, arena, tree, kind, node_base, d_nodes, d_slot, res.n_tree_nodes, res.max_depth, res.tree_box);
+            if (!err.empty()) return err;
+            res.slot_prim.resize(n);
+            HIPCHK(hipMemcpyAsync(res.slot_prim.data(), d_slot, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            res.has_tree = true;
+            for (uint32_t i : big) res.slot_prim.push_back((int32_t)i);
+            return "";
+        }
         if (builder == 2) {
             std::vector<int> h_left, h_right, order;
             std::vector<Box6> h_box;
@@ -850,17 +872,16 @@ std::string buildKind(hipStream_t s, const Box6* d_boxes, const std::vector<Box6
         cinv.y = cb.hi[1] > cb.lo[1] ? 1.0f / (cb.hi[1] - cb.lo[1]) : 0.f;
         cinv.z = cb.hi[2] > cb.lo[2] ? 1.0f / (cb.hi[2] - cb.lo[2]) : 0.f;
 
-        DevBuf<uint32_t> ids, vals_in, vals_out, left, right;
+        DevBuf<uint32_t> vals_in, vals_out, left, right;
         DevBuf<uint64_t> keys_in, keys_out;
         DevBuf<int> first, last, parent, done, newidx;
         DevBuf<Box6> node_box;
         DevBuf<uint32_t> depth;
-        HIPCHK(ids.alloc(n)); HIPCHK(vals_in.alloc(n)); HIPCHK(vals_out.alloc(n));
+        HIPCHK(vals_in.alloc(n)); HIPCHK(vals_out.alloc(n));
         HIPCHK(keys_in.alloc(n)); HIPCHK(keys_out.alloc(n));
         HIPCHK(left.alloc(n)); HIPCHK(right.alloc(n)); HIPCHK(first.alloc(n)); HIPCHK(last.alloc(n));
         HIPCHK(parent.alloc(2 * (size_t)n)); HIPCHK(done.alloc(n)); HIPCHK(newidx.alloc(n));
         HIPCHK(node_box.alloc(2 * (size_t)n)); HIPCHK(depth.alloc(1));
-        HIPCHK(hipMemcpyAsync(ids.p, small.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(k_morton, dim3(nblocks(n)), dim3(BB), 0, s, d_boxes, ids.p, (uint32_t)n, cmin, cinv, keys_in.p, vals_in.p);
         size_t temp_bytes = 0;
         HIPCHK(rocprim::radix_sort_pairs(nullptr, temp_bytes, keys_in.p, keys_out.p, vals_in.p, vals_out.p, (size_t)n, 0, 63, s));
@@ -868,27 +889,34 @@ std::string buildKind(hipStream_t s, const Box6* d_boxes, const std::vector<Box6
         HIPCHK(temp.alloc(temp_bytes));
         HIPCHK(rocprim::radix_sort_pairs(temp.p, temp_bytes, keys_in.p, keys_out.p, vals_in.p, vals_out.p, (size_t)n, 0, 63, s));
         if (builder == 1) {
-            std::vector<int> h_left, h_right, order;
-            std::vector<Box6> h_box;
-            std::vector<BvhNode> h_nodes;
-            int root = 0;
-            std::string err = plocBuild(s, d_boxes, vals_out.p, n, pad, h_left, h_right, h_box, root);
+            // clustering, rotations, leaf collapse and node emission on the device
+            DeviceArena arena;
+            tree_reserve(arena, n);
+            arena.reserve<int>((size_t)n);
+            arena.reserve<int>((size_t)n);
+            arena.reserve<Box6>(2 * (size_t)n);
+            arena.reserve<int>(8);
+            arena.reserve<int32_t>((size_t)n);
+            HIPCHK(arena.commit());
+            DeviceTree tree;
+            tree.n = n;
+            tree.left = arena.take<int>((size_t)n);
+            tree.right = arena.take<int>((size_t)n);
+            tree.box = arena.take<Box6>(2 * (size_t)n);
+            tree.root = arena.take<int>(8);
+            tree.leaf_prim = vals_out.p;
+            int32_t* d_slot = arena.take<int32_t>((size_t)n);
+            if (!tree.left || !tree.right || !tree.box || !tree.root || !d_slot) return "BVH build: work space exhausted";
+            std::string err = plocBuild(s, d_boxes, vals_out.p, n, pad, tree.left, tree.right, tree.box, tree.root);
             if (!err.empty()) return err;
-            uint32_t depth = 0;
-            {
-                HostPass hp(res.host_ms);
-                rotateTree(h_left, h_right, h_box, n, root, BVH_ROTATE_PASSES);
-                emitTree(h_left, h_right, h_box, n, root, kind, node_base, h_nodes, order, depth);
-            }
-            std::vector<uint32_t> h_sorted(n);
-            HIPCHK(hipMemcpyAsync(h_sorted.data(), vals_out.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, s));
-            HIPCHK(hipMemcpyAsync(d_nodes + node_base, h_nodes.data(), sizeof(BvhNode) * h_nodes.size(), hipMemcpyHostToDevice, s));
+            err = tree_rotate(s, arena, tree, BVH_ROTATE_PASSES);
+            if (!err.empty()) return err;
+            err = tree_emit(s, arena, tree, kind, node_base, d_nodes, d_slot, res.n_tree_nodes, res.max_depth, res.tree_box);
+            if (!err.empty()) return err;
+            res.slot_prim.resize(n);
+            HIPCHK(hipMemcpyAsync(res.slot_prim.data(), d_slot, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
-            res.max_depth = depth;
-            res.n_tree_nodes = (uint32_t)h_nodes.size();
             res.has_tree = true;
-            res.tree_box = h_box[root];
-            for (int i = 0; i < n; ++i) res.slot_prim.push_back((int32_t)h_sorted[order[i]]);
             for (uint32_t i : big) res.slot_prim.push_back((int32_t)i);
             return "";
         }
@@ -1222,7 +1250,20 @@ std::string bvh_build(hipStream_t s, const BvhBuildInput& in, BvhBuildOutput& ou
     HIPCHK(hipStreamSynchronize(s));
 
     // 6. the four-wide version of the hierarchy
-    if (out.n_nodes) {
+#ifndef WIDE_HOST_MAX_NODES
+#define WIDE_HOST_MAX_NODES 256u   /* hierarchies of a few nodes: the host loop is quicker than two launches per level */
+#endif
+    if (out.n_nodes > WIDE_HOST_MAX_NODES) {
+        HIPCHK(hipMalloc((void**)&out.wnodes, (size_t)out.n_nodes * sizeof(WideNode)));
+        bool wide_ok = false;
+        const std::string werr = wide_collapse_device(s, out.nodes, out.n_nodes, out.max_depth, MAKE_LEAF(REF_TRI, T, 1u), out.wnodes, out.n_wnodes, out.wide_depth, wide_ok);
+        if (!werr.empty()) return werr;
+        if (!wide_ok) {  // not representable: the kernels fall back to the two-box nodes
+            (void)hipFree(out.wnodes);
+            out.wnodes = nullptr;
+            out.n_wnodes = out.wide_depth = 0;
+        }
+    } else if (out.n_nodes) {
         std::vector<BvhNode> h_bin(out.n_nodes);
         HIPCHK(hipMemcpyAsync(h_bin.data(), out.nodes, sizeof(BvhNode) * out.n_nodes, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));

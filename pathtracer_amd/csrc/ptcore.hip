@@ -857,9 +857,9 @@ int ptc_build(ptc_context* ctx) try {
     in.n_spheres = (uint32_t)ctx->spheres.size();
     in.h_tri_mat = tmat.data();
     in.h_sph_mat = smat.data();
-    // two hierarchies while the host sweep stays well under a second; PLOC alone beyond that
+    // two hierarchies up to the size the sweep builder takes; clustering alone beyond that
     const bool two = ctx->bvh_builder == 3 && ctx->tris.size() + ctx->spheres.size() <= TWO_TREES_MAX_PRIMS;
-    in.builder = ctx->bvh_builder == 3 ? (two ? 2 : 1) : ctx->bvh_builder;
+    in.builder = ctx->bvh_builder == 3 ? (two ? 4 : 1) : ctx->bvh_builder;
     in.extra_extent = ctx->have_cfg ? std::max(fabsf(ctx->cfg.eye.x), std::max(fabsf(ctx->cfg.eye.y), fabsf(ctx->cfg.eye.z))) : 0.f;
     // A hierarchy the traversal stack cannot hold (clustering and sweep follow the geometry, and some geometry
     // makes chains) is built again as a radix tree over the Morton codes, whose depth is bounded by the key length.
@@ -874,7 +874,7 @@ int ptc_build(ptc_context* ctx) try {
         return e;
     };
     std::string err = build(in.builder, ctx->bvh);
-    if (err.empty() && two) {  // closest-hit rays: SAH sweep (above); any-hit rays: PLOC
+    if (err.empty() && two) {  // closest-hit rays: surface-area sweep (above); any-hit rays: clustering
         err = build(1, ctx->bvh_any);
         ctx->two_trees = err.empty();
     }
@@ -1246,7 +1246,7 @@ int ptc_set_option(ptc_context* ctx, int option, int64_t value) try {
         case PTC_OPT_OVERLAP_GATHER: ctx->overlap_gather = value != 0; break;
         case PTC_OPT_SORT_RAYS: ctx->sort_rays = value != 0; break;
         case PTC_OPT_BVH_BUILDER:
-            if (value < 0 || value > 3) return fail(ctx, PTC_ERR_INVALID, "BVH builder must be 0 (LBVH), 1 (PLOC), 2 (SAH sweep on the host) or 3 (2 for closest-hit rays, 1 for any-hit rays)");
+            if (value < 0 || value > 4) return fail(ctx, PTC_ERR_INVALID, "BVH builder must be 0 (LBVH), 1 (PLOC), 2 (surface-area sweep on the host), 4 (the same sweep on the GPU) or 3 (4 for closest-hit rays, 1 for any-hit rays)");
             ctx->bvh_builder = (int)value;
             ctx->built = false;
             break;

@@ -57,7 +57,7 @@ struct BvhBuildInput {
     const uint32_t* h_tri_mat;   // host: material id | light bit per triangle / sphere (upload order)
     const uint32_t* h_sph_mat;
     float extra_extent;          // |coordinate| bound of ray origins outside the geometry (the eye)
-    int builder;                 // 0 = LBVH (Karras radix tree), 1 = PLOC (locally-ordered clustering)
+    int builder;                 // 0 = LBVH (Karras radix tree), 1 = PLOC (locally-ordered clustering), 2 = surface-area sweep on the host, 4 = the same sweep on the device
 };
 
 struct BvhBuildOutput {  // device allocations owned by the caller afterwards

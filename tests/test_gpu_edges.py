@@ -100,7 +100,7 @@ def sphere_cloud(n, seed=3, extra=""):
     return SceneLoader().loadText("\n".join(lines) + "\n" + extra)
 
 
-@pytest.mark.parametrize("builder", [0, 1])
+@pytest.mark.parametrize("builder", [0, 1, 4])
 def test_sphere_hierarchy(builder):
     """150 transformed ellipsoids: the sphere tree (not just the <= 8 sphere top-level leaf of
     the shipped scenes), reflections, point + directional lights."""
@@ -286,7 +286,7 @@ def soup(n_tris, n_spheres, seed, degenerate=False):
     return SceneLoader().loadText("\n".join(lines) + "\n")
 
 
-@pytest.mark.parametrize("builder", [0, 1, 2, 3])
+@pytest.mark.parametrize("builder", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("case", [dict(n_tris=6000, n_spheres=60, seed=11), dict(n_tris=3000, n_spheres=0, seed=12, degenerate=True)])
 def test_random_soups_against_brute_force(case, builder):
     """Camera inside a cloud of small, huge, coincident and zero-area primitives: every
@@ -334,7 +334,7 @@ def test_small_scenes_against_brute_force(n_tris, n_spheres):
             assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (builder, hex(tune))
 
 
-@pytest.mark.parametrize("builder", [0, 1, 2, 3])
+@pytest.mark.parametrize("builder", [0, 1, 2, 3, 4])
 def test_many_coincident_primitives(builder):
     """600 exact copies of one triangle inside a soup (an instanced mesh exported twice, stacked decals ...): the
     clustering and the sweep must pair the copies up evenly -- merged one pair per round, or split off one at a

@@ -221,22 +221,30 @@ def test_pathtracer_glass_and_volume(rel, material, head, semantics, seeding):
 
 
 def test_bvh_builders_agree():
-    """LBVH, PLOC and host-SAH trees, and the pair of trees of builder 3 (SAH for the closest-hit rays, PLOC for the
-    any-hit rays), give the same hits and the same image, bit for bit."""
+    """LBVH, PLOC, the surface-area sweep in host code (2) and on the GPU (4), and the pair of trees of builder 3 (the
+    GPU sweep for the closest-hit rays, PLOC for the any-hit rays), give the same hits and the same image, bit for bit.
+    The GPU sweep makes the same decisions as the host sweep (same costs, same tie rules): its tree has the same number
+    of nodes and costs the rays the same number of node visits and primitive tests (up to the order of the two leaves of
+    a two-primitive node, which the host takes from the parent's axis)."""
     scene = load("scene4/dragon.test", size="160 120", spp="2")
-    out = []
-    for builder in (0, 1, 2, 3):
-        r = Renderer(scene, options={_ffi.OPT_BVH_BUILDER: builder, _ffi.OPT_SEMANTICS: 1, _ffi.OPT_SEEDING: 1})
+    out = {}
+    for builder in (0, 1, 2, 4, 3):
+        r = Renderer(scene, options={_ffi.OPT_BVH_BUILDER: builder, _ffi.OPT_SEMANTICS: 1, _ffi.OPT_SEEDING: 1, _ffi.OPT_COUNT_TRAVERSAL: 1})
         hits = r.primary_hits()
+        r.reset_stats()
         r.run()
-        out.append((hits, r.sums(), r.stats().bvh_nodes))
+        st = r.stats()
+        out[builder] = (hits, r.sums(), st.bvh_nodes, st.nodes_visited, st.prims_tested, st.build_host_ms)
         r.close()
-    assert len({o[2] for o in out}) == 3  # really three different trees (builder 3 reports its closest-hit tree: builder 2's)
-    assert out[3][2] == out[2][2]
-    for other in out[1:]:
+    assert len({out[b][2] for b in (0, 1, 2)}) == 3  # really different trees
+    assert out[3][2] == out[4][2]                    # builder 3 reports its closest-hit tree: builder 4's
+    assert out[4][2] == out[2][2], (out[4][2], out[2][2])
+    assert abs(out[4][3] - out[2][3]) <= 0.002 * out[2][3] and abs(out[4][4] - out[2][4]) <= 0.002 * out[2][4], (out[4][3:5], out[2][3:5])
+    assert out[4][5] == 0.0 and out[1][5] == 0.0 and out[3][5] == 0.0 and out[2][5] > 0.0  # which builds ran host passes over the tree
+    for b in (1, 2, 4, 3):
         for f in ("prim", "t", "u", "v"):
-            assert np.array_equal(out[0][0][f].view(np.uint32), other[0][f].view(np.uint32))
-        assert np.array_equal(out[0][1].view(np.uint32), other[1].view(np.uint32))
+            assert np.array_equal(out[0][0][f].view(np.uint32), out[b][0][f].view(np.uint32)), (b, f)
+        assert np.array_equal(out[0][1].view(np.uint32), out[b][1].view(np.uint32)), b
 
 
 @pytest.mark.parametrize("tune", [0x0020, 0x1120, 0x2220, 0x4420, 0x4408, 0x4440, 0x1320, 0x6620, 0x6608, 0x6640])
