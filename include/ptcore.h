@@ -342,6 +342,14 @@ int  ptc_eval_shading(ptc_context* ctx, int fn, uint32_t n, const float* in16, f
  * launch: loop iterations; lanes owning a ray, visiting a node, standing at a leaf in them; full batches of
  * 64 tests; partial batches and the tests in them. */
 int  ptc_debug_counters(ptc_context* ctx, uint64_t* out, uint32_t n);
+/* Copies of the hierarchy ptc_build made on the device, in the node formats ptc_collapse_wide documents: the
+ * two-child nodes and the four-wide nodes (which == 0: the hierarchy of the closest-hit rays, 1: of the any-hit
+ * rays when PTC_OPT_BVH_BUILDER 3 built one).  Either output may be null; *n_* receive the node counts (0 wide
+ * nodes = that form was not built).  PTC_ERR_INVALID when a non-null output is too small.  An unused child slot
+ * of a device-built wide node holds a leaf reference to the all-zero triangle stored after the scene's (slot =
+ * number of triangles) and an inside-out byte box, not the empty word. */
+int  ptc_debug_hierarchy(ptc_context* ctx, int which, void* binary_out, uint32_t binary_capacity, uint32_t* n_binary,
+                         void* wide_out, uint32_t wide_capacity, uint32_t* n_wide);
 int  ptc_set_option(ptc_context* ctx, int option, int64_t value);
 int  ptc_get_stats(ptc_context* ctx, PtcStats* out);
 int  ptc_reset_stats(ptc_context* ctx);

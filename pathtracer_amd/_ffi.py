@@ -133,6 +133,7 @@ CORE_SYMBOLS = [
     "ptc_render_range", "ptc_resolve", "ptc_primary_hits", "ptc_read_result", "ptc_read_sum",
     "ptc_bind_sum_buffer", "ptc_set_stream", "ptc_synchronize", "ptc_set_option", "ptc_get_stats", "ptc_reset_stats",
     "ptc_collapse_wide", "ptc_render_range_static", "ptc_probe_segments", "ptc_eval_shading", "ptc_debug_counters",
+    "ptc_debug_hierarchy",
 ]
 
 
@@ -166,6 +167,7 @@ def core_lib():
         lib.ptc_probe_segments.argtypes = [vp, u32, vp, vp]
         lib.ptc_eval_shading.argtypes = [vp, C.c_int, u32, vp, vp]
         lib.ptc_debug_counters.argtypes = [vp, vp, u32]
+        lib.ptc_debug_hierarchy.argtypes = [vp, C.c_int, vp, u32, C.POINTER(u32), vp, u32, C.POINTER(u32)]
         lib.ptc_resolve.argtypes = [vp, C.c_int, i32]
         lib.ptc_primary_hits.argtypes = [vp, u32, u32, vp]
         lib.ptc_read_result.argtypes = [vp, vp]

@@ -1287,6 +1287,25 @@ int ptc_debug_counters(ptc_context* ctx, uint64_t* out, uint32_t n) try {
     return caught(ctx, "unknown exception");
 }
 
+int ptc_debug_hierarchy(ptc_context* ctx, int which, void* binary_out, uint32_t binary_capacity, uint32_t* n_binary, void* wide_out, uint32_t wide_capacity,
+                        uint32_t* n_wide) try {
+    ENTER();
+    if (!ctx->built) return fail(ctx, PTC_ERR_NOT_BUILT, "ptc_build has not been called since the last geometry upload");
+    if ((which != 0 && which != 1) || (which == 1 && !ctx->two_trees)) return fail(ctx, PTC_ERR_INVALID, "no such hierarchy");
+    const BvhBuildOutput& b = which ? ctx->bvh_any : ctx->bvh;
+    if (n_binary) *n_binary = b.n_nodes;
+    if (n_wide) *n_wide = b.wnodes ? b.n_wnodes : 0u;
+    if ((binary_out && binary_capacity < b.n_nodes) || (wide_out && b.wnodes && wide_capacity < b.n_wnodes)) return fail(ctx, PTC_ERR_INVALID, "output too small");
+    CHK(hipStreamSynchronize(ctx->stream));
+    if (binary_out && b.n_nodes) CHK(hipMemcpy(binary_out, b.nodes, (size_t)b.n_nodes * sizeof(BvhNode), hipMemcpyDeviceToHost));
+    if (wide_out && b.wnodes && b.n_wnodes) CHK(hipMemcpy(wide_out, b.wnodes, (size_t)b.n_wnodes * sizeof(WideNode), hipMemcpyDeviceToHost));
+    return PTC_OK;
+} catch (const std::exception& e) {
+    return caught(ctx, e.what());
+} catch (...) {
+    return caught(ctx, "unknown exception");
+}
+
 int ptc_get_stats(ptc_context* ctx, PtcStats* out) try {
     ENTER();
     if (!out) return fail(ctx, PTC_ERR_INVALID, "null output");

@@ -135,6 +135,17 @@ class Renderer:
         self._check(self._lib.ptc_eval_shading(self._ctx, fn, len(inputs), inputs.ctypes.data, out.ctypes.data))
         return out
 
+    def hierarchy(self, which: int = 0):
+        """ptc_debug_hierarchy: (two-child nodes, four-wide nodes) of the hierarchy the build left on the device, as
+        structured arrays in the layouts ptc_collapse_wide documents (the wide array is empty when that form was not built)."""
+        BIN = np.dtype([("lo0", "<f4", 3), ("hi0", "<f4", 3), ("lo1", "<f4", 3), ("hi1", "<f4", 3), ("child", "<u4", 2), ("pad", "<u4", 2)])
+        WIDE = np.dtype([("origin", "<f4", 3), ("scale", "<f4", 3), ("qlo", "u1", (3, 4)), ("qhi", "u1", (3, 4)), ("child", "<u4", 4)])
+        nb, nw = C.c_uint32(0), C.c_uint32(0)
+        self._check(self._lib.ptc_debug_hierarchy(self._ctx, which, None, 0, C.byref(nb), None, 0, C.byref(nw)))
+        b, w = np.zeros(nb.value, dtype=BIN), np.zeros(nw.value, dtype=WIDE)
+        self._check(self._lib.ptc_debug_hierarchy(self._ctx, which, b.ctypes.data, len(b), C.byref(nb), w.ctypes.data, len(w), C.byref(nw)))
+        return b, w
+
     def stats(self) -> _ffi.Stats:
         st = _ffi.Stats()
         self._check(self._lib.ptc_get_stats(self._ctx, C.byref(st)))

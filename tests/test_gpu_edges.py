@@ -459,3 +459,58 @@ def test_stats_report_the_batch_footprint():
     assert st.batch_paths == 64 * 64 * 4
     # one quad light -> one light sample per segment: 212 B per path plus alignment slack
     assert 212 * st.batch_paths <= st.path_state_bytes <= 212 * st.batch_paths + 18 * 256
+
+
+@pytest.mark.parametrize("which", [0, 1])
+def test_device_built_wide_nodes(which):
+    """The four-wide nodes the build makes on the GPU, read back: every stored child box contains everything below
+    that child and is no looser than one grid step, every leaf of the two-child hierarchy appears exactly once
+    (the checks of tests/test_wide_nodes.py), and node for node they are what the host-side collapse makes of the same
+    two-child nodes -- same children in the same order, same origin, scale and byte planes; only the numbering of the
+    nodes differs (the device numbers level by level)."""
+    import ctypes as C
+    from test_wide_nodes import EMPTY, WIDE, check
+    scene = SceneLoader().loadText(override_scene_text(scene_text("scene4/dragon.test"), size="64 48", spp="1"))
+    r = Renderer(scene)
+    bin_nodes, wide = r.hierarchy(which)
+    st = r.stats()
+    r.close()
+    assert st.build_host_ms == 0.0 and len(bin_nodes) > 40000 and 0 < len(wide) < len(bin_nodes)
+    unused = (1 << 30) | len(scene.triangles)  # a leaf of one triangle: the all-zero one after the scene's
+    # the same two-child nodes through the host-side collapse
+    lib = _ffi.core_lib()
+    lib.ptc_collapse_wide.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    host = np.zeros(len(bin_nodes), dtype=WIDE)
+    n, depth = C.c_uint32(0), C.c_uint32(0)
+    assert lib.ptc_collapse_wide(bin_nodes.ctypes.data, len(bin_nodes), host.ctypes.data, len(host), C.byref(n), C.byref(depth)) == 0
+    assert n.value == len(wide)
+    todo, visited = [(0, 0)], 0
+    while todo:
+        d, h = todo.pop()
+        visited += 1
+        a, b = wide[d], host[h]
+        assert np.array_equal(a["origin"], b["origin"]) and np.array_equal(a["scale"], b["scale"])
+        for c in range(4):
+            rd, rh = int(a["child"][c]), int(b["child"][c])
+            if rh == EMPTY:
+                assert rd == unused and (a["qlo"][:, c] == 255).all() and (a["qhi"][:, c] == 0).all()
+                continue
+            assert np.array_equal(a["qlo"][:, c], b["qlo"][:, c]) and np.array_equal(a["qhi"][:, c], b["qhi"][:, c])
+            if rh >> 30 == 0:
+                assert rd >> 30 == 0
+                todo.append((rd, rh))
+            else:
+                assert rd == rh
+    assert visited == len(wide)
+    # containment and tightness against the leaf boxes of the two-child nodes
+    boxes = {}
+    for nd in bin_nodes:
+        for c, (lo, hi) in enumerate((("lo0", "hi0"), ("lo1", "hi1"))):
+            ref = int(nd["child"][c])
+            if ref != EMPTY and ref >> 30 != 0:
+                boxes[ref] = (nd[lo].copy(), nd[hi].copy())
+    plain = wide.copy()
+    plain["child"][plain["child"] == unused] = EMPTY
+    import sys
+    sys.setrecursionlimit(10000)
+    check(plain, boxes)
