@@ -13,6 +13,7 @@ struct MultiGpuRenderer::Dev {
     ptc_context* ctx = nullptr;
     hipStream_t stream = nullptr;
     float* sums = nullptr;
+    float* host_sums = nullptr;  // pinned; ordered sum only
     ncclComm_t comm = nullptr;
     std::string error;  // first failure of this device's thread
 };
@@ -40,30 +41,46 @@ MultiGpuRenderer::MultiGpuRenderer(std::shared_ptr<Scene> scene_, int n_devices,
     height = scene->height;
     const size_t bytes = (size_t)width * height * 3 * sizeof(float);
     try {
+        // One host thread per context: uploads and the hierarchy build of every device run side by side
+        // (the scene is replicated; each build is tens of milliseconds of launches and waits on its own device).
         for (int g = 0; g < n_devices; ++g) {
-            Dev* d = new Dev;
-            devs.push_back(d);
-            d->device = g % present;
-            if (ptc_create(d->device, &d->ctx) != PTC_OK) throw std::runtime_error(ptc_last_error(nullptr));
-            hipCheck(hipSetDevice(d->device), "hipSetDevice");
-            hipCheck(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking), "hipStreamCreate");
-            hipCheck(hipMalloc((void**)&d->sums, bytes), "hipMalloc");
-            ptc_context* c = d->ctx;
-            coreCheck(c, ptc_set_stream(c, d->stream));
-            coreCheck(c, ptc_bind_sum_buffer(c, d->sums, bytes));
-            coreCheck(c, ptc_set_option(c, PTC_OPT_SEEDING, 1));  // the image must not depend on the partition
-            // the same uploads as Renderer::buildScene, on every device (the scene is replicated)
-            coreCheck(c, ptc_set_config(c, &scene->config));
-            coreCheck(c, ptc_set_integrator(c, scene->integratorName.c_str()));
-            coreCheck(c, ptc_set_params(c, scene->light_samples, scene->light_stratify, scene->config.next_event_est, scene->sampling_method,
-                                        (int32_t)scene->samples_per_pixel));
-            coreCheck(c, ptc_set_triangles(c, scene->triangles.data(), scene->triangles.size()));
-            coreCheck(c, ptc_set_spheres(c, scene->spheres.data(), scene->spheres.size()));
-            coreCheck(c, ptc_set_lights(c, scene->plights.data(), scene->plights.size(), scene->dlights.data(), scene->dlights.size(),
-                                        scene->qlights.data(), scene->qlights.size()));
-            coreCheck(c, ptc_set_background(c, 0.f, 0.f, 0.f));
-            coreCheck(c, ptc_build(c));
+            devs.push_back(new Dev);
+            devs[g]->device = g % present;
         }
+        auto setUp = [this, bytes](Dev* d) {
+            try {
+                if (ptc_create(d->device, &d->ctx) != PTC_OK) throw std::runtime_error(ptc_last_error(nullptr));
+                hipCheck(hipSetDevice(d->device), "hipSetDevice");
+                hipCheck(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking), "hipStreamCreate");
+                hipCheck(hipMalloc((void**)&d->sums, bytes), "hipMalloc");
+                if (ordered) hipCheck(hipHostMalloc((void**)&d->host_sums, bytes), "hipHostMalloc");
+                ptc_context* c = d->ctx;
+                coreCheck(c, ptc_set_stream(c, d->stream));
+                coreCheck(c, ptc_bind_sum_buffer(c, d->sums, bytes));
+                coreCheck(c, ptc_set_option(c, PTC_OPT_SEEDING, 1));  // the image must not depend on the partition
+                // the same uploads as Renderer::buildScene, on every device
+                coreCheck(c, ptc_set_config(c, &scene->config));
+                coreCheck(c, ptc_set_integrator(c, scene->integratorName.c_str()));
+                coreCheck(c, ptc_set_params(c, scene->light_samples, scene->light_stratify, scene->config.next_event_est, scene->sampling_method,
+                                            (int32_t)scene->samples_per_pixel));
+                coreCheck(c, ptc_set_triangles(c, scene->triangles.data(), scene->triangles.size()));
+                coreCheck(c, ptc_set_spheres(c, scene->spheres.data(), scene->spheres.size()));
+                coreCheck(c, ptc_set_lights(c, scene->plights.data(), scene->plights.size(), scene->dlights.data(), scene->dlights.size(),
+                                            scene->qlights.data(), scene->qlights.size()));
+                coreCheck(c, ptc_set_background(c, 0.f, 0.f, 0.f));
+                coreCheck(c, ptc_build(c));
+            } catch (const std::exception& e) {
+                d->error = e.what();
+            }
+        };
+        {
+            std::vector<std::thread> threads;
+            for (int g = 1; g < n_devices; ++g) threads.emplace_back(setUp, devs[g]);
+            setUp(devs[0]);
+            for (auto& t : threads) t.join();
+        }
+        for (Dev* d : devs)
+            if (!d->error.empty()) throw std::runtime_error("GPU " + std::to_string(d->device) + ": " + d->error);
         if (!ordered) {
             std::vector<ncclComm_t> comms(n_devices);
             std::vector<int> ids(n_devices);
@@ -85,6 +102,7 @@ void MultiGpuRenderer::release() {
         if (d->comm) (void)ncclCommDestroy(d->comm);
         if (d->ctx) (void)ptc_destroy(d->ctx);
         if (d->sums) (void)hipFree(d->sums);
+        if (d->host_sums) (void)hipHostFree(d->host_sums);
         if (d->stream) (void)hipStreamDestroy(d->stream);
         delete d;
     }
@@ -114,17 +132,24 @@ void MultiGpuRenderer::run() {
         if (!d->error.empty()) throw std::runtime_error("GPU " + std::to_string(d->device) + ": " + d->error);
     // 2. combine on device 0
     if (ordered) {
-        std::vector<float> acc(count), part(count);
+        // every device copies its sums to pinned host memory on its own stream, all copies in flight together;
+        // the host then adds them in device order, ((s0 + s1) + s2) + ...
+        for (Dev* d : devs) {
+            hipCheck(hipSetDevice(d->device), "hipSetDevice");
+            hipCheck(hipMemcpyAsync(d->host_sums, d->sums, count * sizeof(float), hipMemcpyDeviceToHost, d->stream), "hipMemcpy");
+        }
+        float* acc = devs[0]->host_sums;
         for (int g = 0; g < G; ++g) {
             Dev* d = devs[g];
             hipCheck(hipSetDevice(d->device), "hipSetDevice");
-            hipCheck(hipMemcpyAsync(g == 0 ? acc.data() : part.data(), d->sums, count * sizeof(float), hipMemcpyDeviceToHost, d->stream), "hipMemcpy");
             hipCheck(hipStreamSynchronize(d->stream), "hipStreamSynchronize");
-            if (g)
-                for (size_t i = 0; i < count; ++i) acc[i] += part[i];  // ((s0 + s1) + s2) + ...
+            if (g) {
+                const float* part = d->host_sums;
+                for (size_t i = 0; i < count; ++i) acc[i] += part[i];
+            }
         }
         hipCheck(hipSetDevice(devs[0]->device), "hipSetDevice");
-        hipCheck(hipMemcpyAsync(devs[0]->sums, acc.data(), count * sizeof(float), hipMemcpyHostToDevice, devs[0]->stream), "hipMemcpy");
+        hipCheck(hipMemcpyAsync(devs[0]->sums, acc, count * sizeof(float), hipMemcpyHostToDevice, devs[0]->stream), "hipMemcpy");
         hipCheck(hipStreamSynchronize(devs[0]->stream), "hipStreamSynchronize");
     } else {
         // one collective; each device's part is ordered after its render by its stream

@@ -262,3 +262,24 @@ def test_bench_ranks_sharing_one_gpu():
     # random walks only
     rays = lambda d: d["value"] * d["ms_per_step"] * d["steps"]
     assert 1.8 < rays(b) / rays(a) < 2.2
+
+
+def test_bench_strong_scaling_command_line_of_the_4k_configuration():
+    """The command line of BASELINE configs[4] -- the dragon at 3840x2160 with 4096 samples per pixel divided among the
+    ranks (--strong --workload dragon_4k --spp 4096) -- rehearsed with two ranks that share this box's one GPU: full
+    image size, full sample count, both ranks sizing their batches from the same free-memory figure at the same moment
+    (a rank whose allocation fails halves its batch and goes on).  The line separates render time from combine time.
+    No scaling is measured here: both ranks time-slice one GPU."""
+    import json
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "dragon_4k", "--spp", "4096", "--strong", "--gpus", "2", "--share-gpu",
+           "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["config"]["spp_total"] == 4096 and d["config"]["spp_per_gpu"] == 2048
+    assert (d["config"]["width"], d["config"]["height"]) == (3840, 2160)
+    paths = 3840 * 2160 * 4096
+    assert abs(d["value"] * 1e6 * d["ms_per_step"] * 1e-3 / d["bounces_per_path"] - paths) < 1e-3 * paths  # every sample of every pixel, once
+    ph = d["phases_ms"]
+    assert ph["render_max"] >= ph["render_min"] > 0 and ph["reduce_max"] > 0 and ph["render_max"] + ph["reduce_max"] <= d["ms_per_step"] * 1.05
