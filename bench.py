@@ -91,6 +91,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="do not measure the Cornell GGX workload after the dragon (default single-GPU run)")
     ap.add_argument("--secondary-steps", type=int, default=5)
+    ap.add_argument("--profile-min-paths", type=int, default=65536,
+                    help="kernels of bounces with fewer live paths are not bracketed by HIP events (1 = every kernel)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--batch", type=int, default=None, help="PTC_OPT_BATCH_PATHS")
     ap.add_argument("--builder", type=int, default=None, help="PTC_OPT_BVH_BUILDER")
@@ -273,7 +275,10 @@ def measure(args, workload, steps, warmup, dist, rank, world, local_rank, shared
     for _ in range(warmup):
         step()
     sync()
-    r.set_option(_ffi.OPT_PROFILE, 1)
+    # HIP events around every kernel of the bounces with at least PROFILE_MIN_PATHS live paths; the long tail of
+    # sub-millisecond launches (the Cornell boxes run hundreds of bounces) is not instrumented: two event records per
+    # kernel cost more there than the kernels
+    r.set_option(_ffi.OPT_PROFILE, args.profile_min_paths)
     r.reset_stats()
     phase["render_s"] = phase["reduce_s"] = 0.0
     sync()
@@ -302,24 +307,26 @@ def measure(args, workload, steps, warmup, dist, rank, world, local_rank, shared
         # kernel class the roofline is quoted on (rank 0's launches).  Times: HIP events on the launch
         # stream, live.  Instruction and byte counts per ray: hardware counters of the same command,
         # committed in pmc_counters.json (they need rocprofv3 --pmc passes of their own).
-        launches = max(int(st.extend_launches), 1)
+        launches = max(int(st.extend_timed_launches), 1)
         extend_s = st.extend_ms * 1e-3
-        rays_per_launch = st.extension_rays / launches
+        rays_per_launch = st.extend_timed_rays / launches
         avg_launch_s = extend_s / launches if extend_s > 0 else 0.0
         # algorithmic bytes per extension ray: the ray (2 x float4 = 32 B) read, the hit (t + ref = 8 B) written,
         # 4 B for the queue slot, 64 B per BVH node visited and 48 B per triangle tested -- served mostly by L1/L2
         b_ext = 44.0 + 64.0 * nodes_per_ray + 48.0 * prims_per_ray
         b_sh = 44.0 + 64.0 * snodes_per_ray + 48.0 * sprims_per_ray
-        on_chip_gbs = (b_ext * st.extension_rays / extend_s / 1e9) if extend_s > 0 else 0.0
+        on_chip_gbs = (b_ext * st.extend_timed_rays / extend_s / 1e9) if extend_s > 0 else 0.0
         q, stale = quoted_counters(workload, args.semantics, overridden)
-        surf_launches = max(int(st.shade_launches), 1)
-        hits_per_launch = st.surface_hits / surf_launches
+        surf_launches = max(int(st.surface_timed_launches), 1)
+        hits_per_launch = st.surface_timed_hits / surf_launches
         surf_avg_s = st.surface_ms * 1e-3 / surf_launches
         kernel_ms = {"extend": round(st.extend_ms, 2), "shadow": round(st.connect_ms, 2), "surface": round(st.surface_ms, 2), "gather": round(st.gather_ms, 2),
                      "other": round(st.other_ms, 2)}
         roofline = {
             "kernel": "extension-ray traversal (k_trace_deferred<false> over four-wide nodes; k_extend_static / k_extend for hierarchies of at most 6 / 64 nodes)",
-            "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": int(st.extend_launches), "rays_per_launch": round(rays_per_launch, 1),
+            "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": int(st.extend_timed_launches), "rays_per_launch": round(rays_per_launch, 1),
+            "timed": f"launches of bounces with at least {args.profile_min_paths} live paths: {int(st.extend_timed_launches)} of {int(st.extend_launches)} launches, "
+                     f"{st.extend_timed_rays / max(st.extension_rays, 1):.4f} of the extension rays",
             "nodes_per_ray": round(nodes_per_ray, 2), "prims_per_ray": round(prims_per_ray, 2),
             "algorithmic_bytes_per_ray": round(b_ext, 1), "algorithmic_bytes_per_launch": round(b_ext * rays_per_launch, 1),
             "on_chip_GBs": round(on_chip_gbs, 1),
@@ -327,7 +334,7 @@ def measure(args, workload, steps, warmup, dist, rank, world, local_rank, shared
             "kernel_ms": kernel_ms,
             "shadow": {"algorithmic_bytes_per_ray": round(b_sh, 1), "nodes_per_ray": round(snodes_per_ray, 2), "prims_per_ray": round(sprims_per_ray, 2),
                        "rays": int(st.shadow_rays)},
-            "surface": {"hits": int(st.surface_hits), "launches": int(st.shade_launches), "hits_per_launch": round(hits_per_launch, 1), "avg_launch_ms": round(surf_avg_s * 1e3, 4)},
+            "surface": {"hits": int(st.surface_timed_hits), "launches": int(st.surface_timed_launches), "hits_per_launch": round(hits_per_launch, 1), "avg_launch_ms": round(surf_avg_s * 1e3, 4)},
         }
         none = {"bound": "valu", "achieved": None, "peak": None, "unit": "G wave-instructions/s", "frac": None, "traffic": None,
                 "note": "no committed counter passes for this workload / override: only event-timed figures"}

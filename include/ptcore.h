@@ -115,6 +115,9 @@ typedef struct PtcStats {
     double   surface_ms, gather_ms; /* the two parts of shade_ms (PTC_OPT_PROFILE)   */
     uint64_t surface_hits;     /* segments that hit something = work items of the surface kernel */
     double   build_host_ms;    /* part of build_ms spent in host code (wall clock): 0 = the hierarchy was built on the GPU */
+    /* the launches PTC_OPT_PROFILE timed (all of them with value 1, those of at least `value` work items otherwise):
+     * extension rays and launches behind extend_ms, hits and launches behind surface_ms */
+    uint64_t extend_timed_rays, extend_timed_launches, surface_timed_hits, surface_timed_launches;
 } PtcStats;
 
 typedef struct ptc_context ptc_context;
@@ -165,7 +168,10 @@ enum {
      * light samples per segment): fewer, larger launches per frame.  A batch holds fewer
      * than 2^30 paths whatever is asked for. */
     PTC_OPT_BATCH_PATHS = 5,
-    /* 1 = bracket every kernel class with HIP events and sum the times. */
+    /* 1 = bracket every kernel with HIP events and sum the times per kernel class; N > 1 = only the
+     * kernels of bounces with at least N live paths (the event records between the sub-millisecond
+     * launches of a long tail of bounces cost more than the kernels they time).  PtcStats says how
+     * many rays / hits and launches the times cover. */
     PTC_OPT_PROFILE = 6,
     /* 1 = count BVH nodes visited / primitives tested per ray (slower). */
     PTC_OPT_COUNT_TRAVERSAL = 7,
@@ -266,7 +272,7 @@ int  ptc_render_range(ptc_context* ctx, int frame_id, uint32_t width, uint32_t h
  * survivor count sizes the next launches) and once more before it returns, so it must NOT be issued on a stream
  * that is being captured into a HIP graph (the waits would fail with hipErrorStreamCaptureUnsupported and
  * invalidate the capture).  One sample of every pixel of the image, padded to whole 64x64
- * pixel blocks, must fit: (176 + 44 x light samples per segment) bytes per padded pixel, i.e. up to
+ * pixel blocks, must fit: (160 + 44 x light samples per segment) bytes per padded pixel, i.e. up to
  * 384x448 pixels with two quad lights; larger images -> PTC_ERR_INVALID with a message that
  * says so.  Scene, lights and options must be set up (ptc_set_*, ptc_build) before, with the ordinary
  * calls.  With reference seeding the range must start at 0 with clear (no per-pixel history is kept
@@ -370,7 +376,7 @@ static_assert(sizeof(PtcPointLight) == 36 && sizeof(PtcDirectionalLight) == 24, 
 static_assert(sizeof(PtcConfig) == 88 && offsetof(PtcConfig, hSize) == 48 &&
               offsetof(PtcConfig, gamma) == 64 && offsetof(PtcConfig, russian_roul) == 80, "Config is 88 bytes");
 static_assert(sizeof(PtcHitRecord) == 16, "HitRecord");
-static_assert(sizeof(PtcStats) == 176 && offsetof(PtcStats, build_host_ms) == 168, "PtcStats is 176 bytes");
+static_assert(sizeof(PtcStats) == 208 && offsetof(PtcStats, build_host_ms) == 168, "PtcStats is 208 bytes");
 #endif
 
 #endif /* PTCORE_H */

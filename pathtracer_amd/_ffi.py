@@ -66,7 +66,8 @@ class Stats(C.Structure):
                 ("shadow_nodes_visited", C.c_uint64), ("shadow_prims_tested", C.c_uint64),
                 ("bvh_nodes", C.c_uint32), ("bvh_max_depth", C.c_uint32), ("build_ms", C.c_double),
                 ("path_state_bytes", C.c_uint64), ("batch_paths", C.c_uint64),
-                ("surface_ms", C.c_double), ("gather_ms", C.c_double), ("surface_hits", C.c_uint64), ("build_host_ms", C.c_double)]
+                ("surface_ms", C.c_double), ("gather_ms", C.c_double), ("surface_hits", C.c_uint64), ("build_host_ms", C.c_double),
+                ("extend_timed_rays", C.c_uint64), ("extend_timed_launches", C.c_uint64), ("surface_timed_hits", C.c_uint64), ("surface_timed_launches", C.c_uint64)]
 
 
 class SceneView(C.Structure):

@@ -153,9 +153,8 @@ struct PathState {
     float4* d_depth_next;
     float4* thr_next;
     float4* L;         // radiance accumulated by this path
-    uint32_t* g_p;     // segments waiting for their light terms: path number | flags (emission rule, constant part present)
+    uint32_t* g_p;     // segments waiting for their light terms: position in the bounce's path state | flags (emission rule, constant part present)
     float4* g_a;       //   constant part (written only when it is not +0)
-    float4* g_thr;     //   throughput before the segment
     float* hit_t;      // closest-hit distance of the current segment
     int32_t* hit_ref;  // see HIT_*
     float* contrib;    // [light sample][capacity] records of three floats: per-shadow-sample f*G terms

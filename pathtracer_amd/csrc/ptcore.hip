@@ -117,6 +117,7 @@ struct ptc_context {
 
     // options
     int semantics = 0, seeding = 0, cull_zero = 1, profile = 0, count_trav = 0, brute_force = 0;
+    uint32_t profile_min_items = 0;             // PTC_OPT_PROFILE > 1: only bounces with at least this many live paths are timed
     uint32_t bounce_cap = 1024;
     uint64_t batch_paths = 512u << 20;
     int bvh_builder = 3;
@@ -230,7 +231,6 @@ size_t carvePaths(char* base, uint32_t capacity, uint32_t S, PathState& ps, uint
     ps.L = (float4*)take(n * sizeof(float4));
     ps.g_p = (uint32_t*)take(n * sizeof(uint32_t));
     ps.g_a = (float4*)take(n * sizeof(float4));
-    ps.g_thr = (float4*)take(n * sizeof(float4));
     ps.hit_t = (float*)take(n * sizeof(float));
     ps.hit_ref = (int32_t*)take(n * sizeof(int32_t));
     ps.contrib = (float*)take(ns * 3 * sizeof(float));
@@ -248,7 +248,7 @@ size_t carvePaths(char* base, uint32_t capacity, uint32_t S, PathState& ps, uint
 
 // Device memory one path of a batch takes (see carvePaths): the packed state twice, L, hit, gather
 // record, two queue entries, and per light sample its term and its shadow-ray record.
-uint64_t bytesPerPath(uint32_t S) { return 2u * 48u + 4u + 16u + 8u + 4u + 32u + 8u + (uint64_t)S * (12u + 32u); }
+uint64_t bytesPerPath(uint32_t S) { return 2u * 48u + 4u + 16u + 8u + 4u + 16u + 8u + (uint64_t)S * (12u + 32u); }
 
 int ensurePaths(ptc_context* ctx, uint32_t capacity, uint32_t contrib_samples) {
     if (ctx->ps.capacity >= capacity && ctx->contrib_samples >= contrib_samples) return PTC_OK;
@@ -297,8 +297,8 @@ struct Timed {  // brackets a launch with events when profiling is on
     int kind;
     hipEvent_t a = nullptr, b = nullptr;
     hipStream_t s;
-    Timed(ptc_context* c_, int kind_, hipStream_t s_ = nullptr) : c(c_), kind(kind_), s(s_ ? s_ : c_->stream) {
-        if (c->profile) {
+    Timed(ptc_context* c_, int kind_, hipStream_t s_ = nullptr, bool on = true) : c(c_), kind(kind_), s(s_ ? s_ : c_->stream) {
+        if (c->profile && on) {
             a = takeEvent(c);
             b = a ? takeEvent(c) : nullptr;
             if (a && b) (void)hipEventRecord(a, s);
@@ -442,6 +442,7 @@ int runBounces(ptc_context* ctx, const RenderParams& rp_frame, const DevScene& s
         rp.init_L = (bounce == 0 && first_is_camera && rp.seeding != 0) ? 1u : 0u;
         rp.camera_rays = (bounce == 0 && first_is_camera) ? 1u : 0u;
         uint32_t* grp = ctx->qcount + 8 * (bounce & 1u);  // {hit count, next count, shadow-ray count, extend work, shadow work, gather count}
+        const bool timed = ctx->profile && count >= ctx->profile_min_items;
         CHK(hipMemsetAsync(grp, 0, 6 * sizeof(uint32_t), ctx->stream));
         if (ctx->sort_rays && bounce >= 1u && count >= 65536u && !ctx->no_alloc) {
             // scattered rays, ordered by origin cell and direction octant.  The four queue / hit arrays are free at
@@ -466,13 +467,17 @@ int runBounces(ptc_context* ctx, const RenderParams& rp_frame, const DevScene& s
             std::swap(ctx->ps.thr, ctx->ps.thr_next);
         }
         {
-            Timed t(ctx, 0);
+            Timed t(ctx, 0, nullptr, timed);
             wf_extend(ctx->stream, rp, sc, ctx->ps, count, grp + 3, ctx->resident_waves, bounce == 0 && first_is_camera, ctx->count_trav != 0, ctx->counters);
         }
         ctx->stats.extension_rays += count;
         ctx->stats.extend_launches++;
+        if (timed) {
+            ctx->stats.extend_timed_rays += count;
+            ctx->stats.extend_timed_launches++;
+        }
         {
-            Timed t(ctx, 3);
+            Timed t(ctx, 3, nullptr, timed);
             wf_compact_hits(ctx->stream, rp, sc, ctx->ps, count, ctx->hitq, grp);
         }
         if (gather_pending) {  // the last bounce's gather reads what this surface kernel overwrites
@@ -480,26 +485,26 @@ int runBounces(ptc_context* ctx, const RenderParams& rp_frame, const DevScene& s
             gather_pending = false;
         }
         {
-            Timed t(ctx, 2);
+            Timed t(ctx, 2, nullptr, timed);
             wf_surface(ctx->stream, rp, sc, ctx->ps, ctx->hitq, grp, count, ctx->npix_pad, sample_begin, ctx->segctr, grp + 1, ctx->gatherq,
                        grp + 5, grp + 2, bounce == 0 && first_is_camera);
         }
         if (S) {
             {
-                Timed t(ctx, 1);
+                Timed t(ctx, 1, nullptr, timed);
                 wf_shadow(ctx->stream, rp, sc_any, ctx->ps, grp + 2, (uint64_t)count * S, grp + 4, ctx->resident_waves, ctx->count_trav != 0, ctx->counters, ctx->counters + 4);
             }
             if (overlap) {
                 CHK(hipEventRecord(ctx->ev_shadow, ctx->stream));
                 CHK(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_shadow, 0));
                 {
-                    Timed t(ctx, 4, ctx->aux_stream);
+                    Timed t(ctx, 4, ctx->aux_stream, timed);
                     wf_gather(ctx->aux_stream, rp, sc, ctx->ps, ctx->gatherq, grp + 5, count);
                 }
                 CHK(hipEventRecord(ctx->ev_gather, ctx->aux_stream));
                 gather_pending = true;
             } else {
-                Timed t(ctx, 4);
+                Timed t(ctx, 4, nullptr, timed);
                 wf_gather(ctx->stream, rp, sc, ctx->ps, ctx->gatherq, grp + 5, count);
             }
             ctx->stats.connect_launches++;
@@ -509,6 +514,10 @@ int runBounces(ptc_context* ctx, const RenderParams& rp_frame, const DevScene& s
         CHK(hipStreamSynchronize(ctx->stream));
         CHK(hipGetLastError());
         ctx->stats.surface_hits += ctx->h_count[0];
+        if (timed) {
+            ctx->stats.surface_timed_hits += ctx->h_count[0];
+            ctx->stats.surface_timed_launches++;
+        }
         count = ctx->h_count[1];
         // the survivors' packed state becomes the current one
         std::swap(ctx->ps.o_seed, ctx->ps.o_seed_next);
@@ -1239,7 +1248,11 @@ int ptc_set_option(ptc_context* ctx, int option, int64_t value) try {
             if (value < 1) return fail(ctx, PTC_ERR_INVALID, "batch size must be positive");
             ctx->batch_paths = (uint64_t)value;
             break;
-        case PTC_OPT_PROFILE: ctx->profile = value != 0; break;
+        case PTC_OPT_PROFILE:
+            if (value < 0 || value > 0x7FFFFFFF) return fail(ctx, PTC_ERR_INVALID, "bad profile option");
+            ctx->profile = value != 0;
+            ctx->profile_min_items = value > 1 ? (uint32_t)value : 0u;
+            break;
         case PTC_OPT_COUNT_TRAVERSAL: ctx->count_trav = value != 0; break;
         case PTC_OPT_BRUTE_FORCE: ctx->brute_force = value != 0; break;
         case PTC_OPT_GROUP_HITS: ctx->group_hits = value != 0; break;

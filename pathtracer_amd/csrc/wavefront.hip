@@ -41,6 +41,9 @@
 #include <algorithm>
 
 #define BLOCK TRAV_BLOCK
+#ifndef PT_SHADING_FAST
+#define PT_SHADING_FAST 1   /* 0: correctly rounded division / square root in every shading kernel (A/B builds) */
+#endif
 #define GEN_BLOCK 1024   /* generate / shade: one queue atomic per 1024 paths */
 
 // ---------------------------------------------------------------- helpers --
@@ -898,9 +901,10 @@ __device__ __forceinline__ bool samples_lights(const RenderParams& rp, uint32_t 
 // Light sample q of a segment: the shadow ray and the term the reference adds when that
 // ray is unoccluded (f_brdf*G for the quad-light integrators, the Blinn-Phong term for
 // `raytracer`).
-template <int INTEG>
+template <int INTEG, bool FAST = false>
 __device__ __forceinline__ vec3 light_sample(const RenderParams& rp, const DevScene& sc, const HitAttr& at, const PtcMaterialValue& mv, uint32_t seed, uint32_t q,
                                              vec3& sh_o, vec3& sh_d, float& sh_tmax) {
+    typedef ShMath<FAST> M;  // FAST only ever with INT_PATHTRACER
     const PtcConfig& cf = rp.cf;
     vec3 term = mk3(0.f);
     if (INTEG == INT_RAYTRACER) {
@@ -947,8 +951,15 @@ __device__ __forceinline__ vec3 light_sample(const RenderParams& rp, const DevSc
     const float u2 = rnd(st);
     const vec3 light_pos = quad_sample(qf, rp.light_stratify != 0u, si, sj, root, u1, u2, INTEG == INT_PATHTRACER2);
     sh_o = at.P;
-    sh_d = normalize(light_pos - sh_o);
-    sh_tmax = length(light_pos - sh_o) - cf.epsilon;
+    if (FAST) {  // one reciprocal square root for the direction and the distance
+        const vec3 to_light = light_pos - sh_o;
+        const float d2 = dot(to_light, to_light), inv_len = __builtin_amdgcn_rsqf(d2);
+        sh_d = to_light * inv_len;
+        sh_tmax = d2 * inv_len - cf.epsilon;
+    } else {
+        sh_d = normalize(light_pos - sh_o);
+        sh_tmax = length(light_pos - sh_o) - cf.epsilon;
+    }
     if (INTEG == INT_DIRECT) {
         // RayTracer.cu:204-221
         const vec3 wdir = normalize(light_pos - sh_o);
@@ -962,25 +973,27 @@ __device__ __forceinline__ vec3 light_sample(const RenderParams& rp, const DevSc
         term = f_brdf * G;
     } else if (INTEG == INT_PATHTRACER) {
         // RayTracer.cu:745-776
-        const vec3 n = normalize(at.normal);
-        const vec3 rr = normalize(reflect(-at.wo, at.normal));
-        const vec3 w_i_dir = normalize(light_pos - sh_o);
+        const vec3 n = normalize(at.normal);  // exact in either flavour: see ggx_brdf
+        const vec3 rr = M::normalize(reflect(-at.wo, at.normal));
+        // normalize(light_pos - sh_o) is formed four times in the source, with the same value each time
+        const vec3 to_light = light_pos - sh_o;
+        const vec3 w_i_dir = sh_d;
         vec3 f_brdf = mk3(.0f);
         if (mv.brdf_type == PTC_MOD_PHONG) {
-            f_brdf = phong_brdf(w_i_dir, rr, mv.shininess, P3v(mv.diffuse), P3v(mv.specular));
+            f_brdf = phong_brdf<FAST>(w_i_dir, rr, mv.shininess, P3v(mv.diffuse), P3v(mv.specular));
         } else {
             const float wi_dot_n_dir = dot(w_i_dir, n);
             const float wo_dot_n_dir = dot(at.wo, n);
             if (wi_dot_n_dir > .0f && wo_dot_n_dir > .0f) {
-                const vec3 f_brdf_GGX = ggx_brdf(w_i_dir, at.wo, n, mv.roughness, P3v(mv.specular));
+                const vec3 f_brdf_GGX = ggx_brdf<FAST>(w_i_dir, at.wo, n, mv.roughness, P3v(mv.specular));
                 f_brdf = (P3v(mv.diffuse) / PT_PIf) + f_brdf_GGX;
             }
         }
         const vec3 n_geo = at.normal;  // the inner `n` of :767, not normalised
-        const vec3 n_light = normalize(cross(qf.ab, qf.ac));
-        const float R = length(sh_o - light_pos);
-        const float G = (1.0f / powf(R, 2.0f)) * fmaxf(dot(n_geo, normalize(light_pos - sh_o)), .0f) *
-                        (fmaxf(dot(n_light, normalize(light_pos - sh_o)), .0f));
+        const vec3 n_light = M::normalize(cross(qf.ab, qf.ac));
+        // 1 / R^2 with R = length(sh_o - light_pos): the reciprocal of the squared length, without the root
+        const float inv_R2 = FAST ? M::rcp(dot(to_light, to_light)) : 1.0f / powf(length(sh_o - light_pos), 2.0f);
+        const float G = inv_R2 * fmaxf(dot(n_geo, w_i_dir), .0f) * (fmaxf(dot(n_light, w_i_dir), .0f));
         term = f_brdf * G;
     } else if (INTEG == INT_PATHTRACER2) {
         // RayTracer.cu:410-420
@@ -1239,12 +1252,14 @@ __device__ __forceinline__ float sample_phase_hg(float g, float zeta) {
 }
 
 // RayTracer.cu:496-963, all three material types, without the light sum (gather_pathtracer).
+template <bool FAST = false>
 __device__ __forceinline__ SurfaceOut surface_pathtracer(const RenderParams& rp, const DevScene& sc, const HitAttr& at, Segment& sg) {
+    typedef ShMath<FAST> M;
     const PtcMaterialValue& mv = material_of(sc, at.mat);
     const PtcConfig& cf = rp.cf;
-    const vec3 n = normalize(at.normal);
+    const vec3 n = normalize(at.normal);  // exact in either flavour: see ggx_brdf
     const vec3 L_e = P3v(mv.emission), K_s = P3v(mv.specular), K_d = P3v(mv.diffuse);
-    const vec3 r = normalize(reflect(-at.wo, at.normal));
+    const vec3 r = M::normalize(reflect(-at.wo, at.normal));
     PolarAngle theta = angle_zero();
     float phi = .0f;  // in turns
     vec3 w_i = mk3(.0f);
@@ -1258,17 +1273,17 @@ __device__ __forceinline__ SurfaceOut surface_pathtracer(const RenderParams& rp,
     }
     uint32_t st = sg.seed;
     const float zeta_0 = rnd(st), zeta_1 = rnd(st), zeta_2 = rnd(st);
-    const float K_s_avg = (K_s.x + K_s.y + K_s.z) / 3.0f;
-    const float K_d_avg = (K_d.x + K_d.y + K_d.z) / 3.0f;
+    const float K_s_avg = FAST ? (K_s.x + K_s.y + K_s.z) * (1.0f / 3.0f) : (K_s.x + K_s.y + K_s.z) / 3.0f;
+    const float K_d_avg = FAST ? (K_d.x + K_d.y + K_d.z) * (1.0f / 3.0f) : (K_d.x + K_d.y + K_d.z) / 3.0f;
     float t = .0f;
     if ((K_s_avg == .0f) && (K_d_avg == .0f)) {  // :546-553
         if (mv.brdf_type == PTC_MOD_PHONG) t = .0f;
         else if (mv.brdf_type == PTC_GGX) t = 1.0f;
     } else {
-        const float k_val = K_s_avg / (K_s_avg + K_d_avg);
+        const float k_val = M::div(K_s_avg, K_s_avg + K_d_avg);
         t = mv.brdf_type == PTC_MOD_PHONG ? k_val : fmaxf(.25f, k_val);
     }
-    compute_polar_angles(rp.semantics, rp.sampling_method, phi, theta, zeta_0, zeta_1, zeta_2, t, mv.shininess);  // :566
+    compute_polar_angles<FAST>(rp.semantics, rp.sampling_method, phi, theta, zeta_0, zeta_1, zeta_2, t, mv.shininess);  // :566
 
     if (mv.matType == PTC_GLASS) {  // :574-621
         const vec3 inc_ray_dir = -at.wo;
@@ -1309,14 +1324,14 @@ __device__ __forceinline__ SurfaceOut surface_pathtracer(const RenderParams& rp,
     } else if (mv.brdf_type == PTC_MOD_PHONG) {  // :675-684
         const vec3 w = ((zeta_0 <= t) && (rp.sampling_method == PTC_BRDF_SAMPLING)) ? r : n;
         vec3 u = mk3(.0f), v = mk3(.0f);
-        gen_coord_frame(rp.semantics, w, u, v);
-        w_i = spherical_dir(theta, phi, u, v, w);
+        gen_coord_frame<FAST>(rp.semantics, w, u, v);
+        w_i = spherical_dir<FAST>(theta, phi, u, v, w);
     } else {  // :685-696
-        const PolarAngle theta_h_sample = angle_atan((mv.roughness * sqrtf(zeta_1)) / sqrtf(1.0f - zeta_1), rp.semantics != 1);
+        const PolarAngle theta_h_sample = angle_atan<FAST>(M::div(mv.roughness * M::sqrt(zeta_1), M::sqrt(1.0f - zeta_1)), rp.semantics != 1);
         const float phi_h_sample = zeta_2;  // in turns: 2*pi*zeta_2 (:687)
         vec3 u_h = mk3(.0f), v_h = mk3(.0f);
-        gen_coord_frame(rp.semantics, n, u_h, v_h);
-        w_i = normalize(reflect(-at.wo, spherical_dir(theta_h_sample, phi_h_sample, u_h, v_h, n)));
+        gen_coord_frame<FAST>(rp.semantics, n, u_h, v_h);
+        w_i = M::normalize(reflect(-at.wo, spherical_dir<FAST>(theta_h_sample, phi_h_sample, u_h, v_h, n)));
     }
 
     if (cf.next_event_est) st = lcg_skip(st, 2u * rp.root_light_samples * rp.root_light_samples * sc.n_qlights);  // the u1,u2 of every light sample (:724-725)
@@ -1325,33 +1340,34 @@ __device__ __forceinline__ SurfaceOut surface_pathtracer(const RenderParams& rp,
     float pdf = 1.0f;
     switch (rp.sampling_method) {  // :811-897
         case PTC_HEMISPHERE_SAMPLING:
-            f_brdf = (P3v(mv.diffuse) / PT_PIf) + (P3v(mv.specular) * ((mv.shininess + 2.0f) / (2.0f * PT_PIf)) * pow_pos(fmaxf(dot(r, w_i), .0f), mv.shininess));
+            f_brdf = phong_brdf<FAST>(w_i, r, mv.shininess, P3v(mv.diffuse), P3v(mv.specular));  // the same expression, inline in the source (:813)
             pdf = 1.0f / (2.0f * PT_PIf);
             addon_throughput = (f_brdf * fmaxf(dot(n, w_i), .0f) * (1.0f / pdf));
             break;
         case PTC_COSINE_SAMPLING:
-            f_brdf = (P3v(mv.diffuse) / PT_PIf) + (P3v(mv.specular) * ((mv.shininess + 2.0f) / (2.0f * PT_PIf)) * pow_pos(fmaxf(dot(r, w_i), .0f), mv.shininess));
-            pdf = fmaxf(dot(n, w_i), .0f) / (PT_PIf);
-            addon_throughput = (f_brdf)*fmaxf(dot(n, w_i), .0f) * (1.0f / pdf);
+            f_brdf = phong_brdf<FAST>(w_i, r, mv.shininess, P3v(mv.diffuse), P3v(mv.specular));  // (:822)
+            pdf = FAST ? fmaxf(dot(n, w_i), .0f) * (1.0f / PT_PIf) : fmaxf(dot(n, w_i), .0f) / (PT_PIf);
+            addon_throughput = (f_brdf)*fmaxf(dot(n, w_i), .0f) * M::rcp(pdf);
             break;
         case PTC_BRDF_SAMPLING:
             // The probe shadow rays of :831-860 only feed locals that are never read
             // again; they cannot change the payload and are not traced.
             if (mv.brdf_type == PTC_MOD_PHONG) {
-                f_brdf = phong_brdf(w_i, r, mv.shininess, K_d, K_s);
-                pdf = ((1.0f - t) * (dot(n, w_i) / PT_PIf)) + t * ((mv.shininess + 1.0f) / (2.0f * PT_PIf)) * pow_pos(fmaxf(dot(r, w_i), .0f), mv.shininess);
+                f_brdf = phong_brdf<FAST>(w_i, r, mv.shininess, K_d, K_s);
+                pdf = FAST ? ((1.0f - t) * (dot(n, w_i) * (1.0f / PT_PIf))) + t * ((mv.shininess + 1.0f) * (1.0f / (2.0f * PT_PIf))) * pow_pos(fmaxf(dot(r, w_i), .0f), mv.shininess)
+                           : ((1.0f - t) * (dot(n, w_i) / PT_PIf)) + t * ((mv.shininess + 1.0f) / (2.0f * PT_PIf)) * pow_pos(fmaxf(dot(r, w_i), .0f), mv.shininess);
             } else {
                 const float wi_dot_n = dot(w_i, n);
                 const float wo_dot_n = dot(at.wo, n);
                 if (wi_dot_n > .0f && wo_dot_n > .0f) {
-                    const vec3 h = normalize(w_i + at.wo);
-                    f_brdf = (K_d / PT_PIf) + ggx_brdf(w_i, at.wo, n, mv.roughness, K_s);
-                    pdf = ggx_pdf(w_i, n, h, t, mv.roughness);
+                    const vec3 h = normalize(w_i + at.wo);  // exact, as inside ggx_brdf
+                    f_brdf = (K_d / PT_PIf) + ggx_brdf<FAST>(w_i, at.wo, n, mv.roughness, K_s);
+                    pdf = ggx_pdf<FAST>(w_i, n, h, t, mv.roughness);
                 } else {
                     f_brdf = mk3(.0f);
                 }
             }
-            addon_throughput = (f_brdf * fmaxf(dot(n, w_i), .0f) * (1.0f / pdf));
+            addon_throughput = (f_brdf * fmaxf(dot(n, w_i), .0f) * M::rcp(pdf));
             break;
         default:
             break;
@@ -1367,7 +1383,7 @@ __device__ __forceinline__ SurfaceOut surface_pathtracer(const RenderParams& rp,
     if (cf.russian_roul) {  // :923-933, q from the throughput BEFORE this bounce's factor
         const float q = 1.0f - fminf(fmaxf(fmaxf(sg.thr.x, sg.thr.y), sg.thr.z), 1.0f);
         if (rnd(st) < q) addon_throughput *= mk3(.0f);
-        else addon_throughput *= (1.0f / (1.0f - q));
+        else addon_throughput *= M::rcp(1.0f - q);
     }
     if (mv.matType != PTC_GLASS) sg.thr *= addon_throughput;  // :935-941 (glass: times 1)
     // :943-957; glass never assigns new_pos, so its path continues from (0,0,0)
@@ -1432,7 +1448,9 @@ __device__ __forceinline__ vec3 gather_radiance(const RenderParams& rp, const De
 #define MAT_WORDS (sizeof(PtcMaterialValue) / 4u)
 #define QLIGHT_LDS_MAX 8u   /* the quad lights travel with the materials: their corners are read once per light sample */
 #define QLIGHT_WORDS (sizeof(PtcQuadLight) / 4u)
-template <int INTEG, bool MATS = false>
+// FAST: the shading arithmetic takes the hardware's reciprocal / square root / reciprocal square root (ShMath); the
+// path tracer under `intended` semantics only.
+template <int INTEG, bool MATS = false, bool FAST = false>
 __global__ __launch_bounds__(SURF_BLOCK_MANY, SURF_WAVES) void k_surface(RenderParams rp, DevScene sc_global, PathState ps, const uint32_t* __restrict__ queue,
                                                        const uint32_t* __restrict__ count_ptr, uint32_t npix_pad, uint32_t sample_begin, uint32_t* __restrict__ segctr,
                                                        uint32_t* __restrict__ next_count,
@@ -1501,7 +1519,7 @@ __global__ __launch_bounds__(SURF_BLOCK_MANY, SURF_WAVES) void k_surface(RenderP
             for (uint32_t q = 0; q < 2u; ++q) {
                 f_o[q] = f_d[q] = mk3(0.f);
                 if (sample && q < rp.samples_per_path) {
-                    const vec3 term = light_sample<INTEG>(rp, sc, at, material_of(sc, at.mat), sg.seed, q, f_o[q], f_d[q], f_tmax[q]);
+                    const vec3 term = light_sample<INTEG, FAST>(rp, sc, at, material_of(sc, at.mat), sg.seed, q, f_o[q], f_d[q], f_tmax[q]);
                     f_need[q] = !(term.x == 0.f && term.y == 0.f && term.z == 0.f);
                     f_slot[q] = contrib_slot(ps, i, q);
                     contrib_store(ps, f_slot[q], term);
@@ -1525,7 +1543,7 @@ __global__ __launch_bounds__(SURF_BLOCK_MANY, SURF_WAVES) void k_surface(RenderP
                     need_ray[k] = false;
                     slot[k] = 0;
                     if (sample && q < rp.samples_per_path) {
-                        const vec3 term = light_sample<INTEG>(rp, sc, at, material_of(sc, at.mat), sg.seed, q, sh_o[k], sh_d[k], sh_tmax[k]);
+                        const vec3 term = light_sample<INTEG, FAST>(rp, sc, at, material_of(sc, at.mat), sg.seed, q, sh_o[k], sh_d[k], sh_tmax[k]);
                         need_ray[k] = !(term.x == 0.f && term.y == 0.f && term.z == 0.f);
                         slot[k] = contrib_slot(ps, i, q);
                         contrib_store(ps, slot[k], term);
@@ -1551,7 +1569,7 @@ __global__ __launch_bounds__(SURF_BLOCK_MANY, SURF_WAVES) void k_surface(RenderP
         else if (INTEG == INT_ANALYTICDIRECT) out = surface_analytic(rp, sc, at, sg);
         else if (INTEG == INT_DIRECT) out = surface_direct(rp, sc, at, sg);
         else if (INTEG == INT_PATHTRACER2) out = surface_pathtracer2(rp, sc, at, sg);
-        else out = surface_pathtracer(rp, sc, at, sg);
+        else out = surface_pathtracer<FAST>(rp, sc, at, sg);
         gather = out.gather && sample;
         if (gather) {
             // w: does the first-hit rule of pathTracer include the emission (:900-903)
@@ -1560,10 +1578,11 @@ __global__ __launch_bounds__(SURF_BLOCK_MANY, SURF_WAVES) void k_surface(RenderP
             // first hit, nothing later with next-event estimation), and only then is its record written and read
             const bool a_set = !(out.a.x == 0.f && out.a.y == 0.f && out.a.z == 0.f) || __builtin_signbitf(out.a.x) || __builtin_signbitf(out.a.y) ||
                                __builtin_signbitf(out.a.z);
-            ps.g_p[i] = p | ((!rp.cf.next_event_est || depth_before == 0u) ? GATHER_WITH_LE : 0u) | (a_set ? GATHER_A_SET : 0u);
+            // The word holds the segment's position in this bounce's packed path state, not the path number: the throughput
+            // before the segment and the path number are in that state's record, which stays as it is until the next
+            // bounce's surface kernel runs -- and that kernel waits for this bounce's gather.
+            ps.g_p[i] = at_state | ((!rp.cf.next_event_est || depth_before == 0u) ? GATHER_WITH_LE : 0u) | (a_set ? GATHER_A_SET : 0u);
             if (a_set) ps.g_a[i] = make_float4(out.a.x, out.a.y, out.a.z, 0.f);
-            // the throughput before the segment; camera segments all have (1, 1, 1): nothing is stored for them
-            if (!first_bounce) ps.g_thr[i] = make_float4(thr_before.x, thr_before.y, thr_before.z, 0.f);
         } else {
             // gather wanted but there is not a single light sample (lightsamples 0): the same
             // formulas over zero terms, here
@@ -1633,8 +1652,11 @@ __global__ __launch_bounds__(GATHER_BLOCK) void k_gather(RenderParams rp, DevSce
     const uint32_t seg = gather_queue[i];  // position in the hit queue
     const uint32_t word = ps.g_p[seg];
     const float4 a4 = (word & GATHER_A_SET) ? ps.g_a[seg] : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 t4 = rp.camera_rays ? make_float4(1.f, 1.f, 1.f, 0.f) : ps.g_thr[seg];
-    const uint32_t p = word & ~(GATHER_WITH_LE | GATHER_A_SET);
+    // throughput before the segment and path number: the segment's record in the bounce's path state (camera segments:
+    // throughput 1, path number in an array of its own)
+    const uint32_t at_state = word & ~(GATHER_WITH_LE | GATHER_A_SET);
+    const float4 t4 = rp.camera_rays ? make_float4(1.f, 1.f, 1.f, 0.f) : ps.thr[at_state];
+    const uint32_t p = rp.camera_rays ? ps.pid[at_state] : f2u(t4.w);
     const vec3 a = mk3(a4.x, a4.y, a4.z), thr = mk3(t4.x, t4.y, t4.z);
     const vec3 radiance = gather_radiance<INTEG>(rp, sc, ps, seg, a, thr, (word & GATHER_WITH_LE) != 0u);
     float4 L = rp.init_L ? make_float4(0.f, 0.f, 0.f, 0.f) : ps.L[p];
@@ -1725,25 +1747,28 @@ __global__ __launch_bounds__(BLOCK) void k_eval_shading(int fn, uint32_t n, cons
     const float* a = in + 16 * (size_t)i;
     const vec3 v0 = mk3(a[0], a[1], a[2]), v1 = mk3(a[3], a[4], a[5]), v2 = mk3(a[6], a[7], a[8]), v3 = mk3(a[9], a[10], a[11]);
     vec3 r = mk3(0.f);
+    // the flavour the path tracer runs under `intended` semantics
+    constexpr bool F = PT_SHADING_FAST != 0;
+    typedef ShMath<F> M;
     if (fn == 0) {
-        r = phong_brdf(v0, v1, a[12], v2, v3);
+        r = phong_brdf<F>(v0, v1, a[12], v2, v3);
     } else if (fn == 1) {
-        r = ggx_brdf(v0, v1, v2, a[12], v3);
+        r = ggx_brdf<F>(v0, v1, v2, a[12], v3);
     } else if (fn == 2) {
-        r = mk3(ggx_pdf(v0, v1, v2, a[12], a[13]), 0.f, 0.f);
+        r = mk3(ggx_pdf<F>(v0, v1, v2, a[12], a[13]), 0.f, 0.f);
     } else if (fn == 3) {
         PolarAngle theta = angle_zero();
         float phi = 0.f;
-        compute_polar_angles(1, (uint32_t)a[8], phi, theta, a[3], a[4], a[5], a[6], a[7]);
+        compute_polar_angles<F>(1, (uint32_t)a[8], phi, theta, a[3], a[4], a[5], a[6], a[7]);
         vec3 u = mk3(0.f), v = mk3(0.f);
-        gen_coord_frame(1, v0, u, v);
-        r = spherical_dir(theta, phi, u, v, v0);
+        gen_coord_frame<F>(1, v0, u, v);
+        r = spherical_dir<F>(theta, phi, u, v, v0);
     } else if (fn == 4) {
         const float zeta_1 = a[6], zeta_2 = a[7], roughness = a[8];
-        const PolarAngle theta_h = angle_atan((roughness * sqrtf(zeta_1)) / sqrtf(1.0f - zeta_1), false);
+        const PolarAngle theta_h = angle_atan<F>(M::div(roughness * M::sqrt(zeta_1), M::sqrt(1.0f - zeta_1)), false);
         vec3 u = mk3(0.f), v = mk3(0.f);
-        gen_coord_frame(1, v0, u, v);
-        r = normalize(reflect(-v1, spherical_dir(theta_h, zeta_2, u, v, v0)));
+        gen_coord_frame<F>(1, v0, u, v);
+        r = M::normalize(reflect(-v1, spherical_dir<F>(theta_h, zeta_2, u, v, v0)));
     }
     out[4 * (size_t)i] = r.x;
     out[4 * (size_t)i + 1] = r.y;
@@ -1912,6 +1937,7 @@ void wf_compact_hits(hipStream_t s, const RenderParams& rp, const DevScene& sc, 
 #ifndef MAT_LDS_OFF
 #define MAT_LDS_OFF 0
 #endif
+
 // `count_ptr` (device) holds the number of queued paths; `max_count` bounds it and sizes the grid.
 void wf_surface(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, const uint32_t* count_ptr,
                 uint32_t max_count, uint32_t npix_pad, uint32_t sample_begin, uint32_t* segctr, uint32_t* next_count,
@@ -1920,23 +1946,30 @@ void wf_surface(hipStream_t s, const RenderParams& rp, const DevScene& sc, const
     const uint32_t block = rp.samples_per_path <= 2u ? SURF_BLOCK_FEW : SURF_BLOCK_MANY;
     const dim3 g(blocks_for(max_count, block)), b(block);
     const bool mats = !MAT_LDS_OFF && sc.n_materials != 0u && sc.n_materials <= MAT_LDS_MAX && sc.n_qlights <= QLIGHT_LDS_MAX;
-#define PT_SURFACE(I)                                                                                                                                          \
-    do {                                                                                                                                                       \
-        if (mats)                                                                                                                                              \
-            hipLaunchKernelGGL((k_surface<I, true>), g, b, 0, s, rp, sc, ps, queue, count_ptr, npix_pad, sample_begin, segctr, next_count, gather_queue,      \
-                               gather_count, shadow_count, first_bounce ? 1u : 0u);                                                                            \
-        else                                                                                                                                                   \
-            hipLaunchKernelGGL((k_surface<I, false>), g, b, 0, s, rp, sc, ps, queue, count_ptr, npix_pad, sample_begin, segctr, next_count, gather_queue,     \
-                               gather_count, shadow_count, first_bounce ? 1u : 0u);                                                                            \
+#define PT_SURFACE_LAUNCH(I, M, F)                                                                                                                            \
+    hipLaunchKernelGGL((k_surface<I, M, F>), g, b, 0, s, rp, sc, ps, queue, count_ptr, npix_pad, sample_begin, segctr, next_count, gather_queue, gather_count, \
+                       shadow_count, first_bounce ? 1u : 0u)
+#define PT_SURFACE(I)                           \
+    do {                                        \
+        if (mats) PT_SURFACE_LAUNCH(I, true, false);  \
+        else PT_SURFACE_LAUNCH(I, false, false);      \
     } while (0)
+    // hardware reciprocal / square root in the shading arithmetic: the path tracer under `intended` semantics
+    // (`literal` keeps the correctly rounded operations: there a last bit decides between 1 and NaN)
+    const bool fast = PT_SHADING_FAST && rp.semantics == 1;
     switch (rp.integrator) {
         case INT_RAYTRACER: PT_SURFACE(INT_RAYTRACER); break;
         case INT_ANALYTICDIRECT: PT_SURFACE(INT_ANALYTICDIRECT); break;
         case INT_DIRECT: PT_SURFACE(INT_DIRECT); break;
-        case INT_PATHTRACER: PT_SURFACE(INT_PATHTRACER); break;
+        case INT_PATHTRACER:
+            if (fast && mats) PT_SURFACE_LAUNCH(INT_PATHTRACER, true, true);
+            else if (fast) PT_SURFACE_LAUNCH(INT_PATHTRACER, false, true);
+            else PT_SURFACE(INT_PATHTRACER);
+            break;
         case INT_PATHTRACER2: PT_SURFACE(INT_PATHTRACER2); break;
         default: break;
     }
+#undef PT_SURFACE_LAUNCH
 #undef PT_SURFACE
 }
 

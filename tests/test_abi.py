@@ -33,7 +33,7 @@ def test_pod_sizes_match_the_header():
     assert C.sizeof(_ffi.QuadLight) == 284 and _ffi.QuadLight.color.offset == 272
     assert C.sizeof(_ffi.Config) == 88 and _ffi.Config.hSize.offset == 48 and _ffi.Config.russian_roul.offset == 80
     assert C.sizeof(_ffi.PointLight) == 36 and C.sizeof(_ffi.DirectionalLight) == 24
-    assert C.sizeof(_ffi.Stats) == 8 * 6 + 8 * 4 + 8 * 4 + 4 * 2 + 8 + 8 * 2 + 8 * 4 and _ffi.Stats.build_host_ms.offset == 168
+    assert C.sizeof(_ffi.Stats) == 8 * 6 + 8 * 4 + 8 * 4 + 4 * 2 + 8 + 8 * 2 + 8 * 4 + 8 * 4 and _ffi.Stats.build_host_ms.offset == 168
 
 
 def test_no_gpu_means_a_loud_error():

@@ -457,8 +457,8 @@ def test_stats_report_the_batch_footprint():
     st = r.stats()
     r.close()
     assert st.batch_paths == 64 * 64 * 4
-    # one quad light -> one light sample per segment: 212 B per path plus alignment slack
-    assert 212 * st.batch_paths <= st.path_state_bytes <= 212 * st.batch_paths + 18 * 256
+    # one quad light -> one light sample per segment: 196 B per path plus alignment slack
+    assert 196 * st.batch_paths <= st.path_state_bytes <= 196 * st.batch_paths + 17 * 256
 
 
 @pytest.mark.parametrize("which", [0, 1])

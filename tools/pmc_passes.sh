@@ -17,6 +17,6 @@ for pmc in \
   "SQ_WAVES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INST_LEVEL_VMEM TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum"
 do
   i=$((i+1))
-  timeout -s KILL 300 rocprofv3 --pmc $pmc --output-format csv -d "$out/pass$i" -- python3 $root/bench.py --no-cpu-baseline --no-secondary --steps 1 --warmup 0 "$@" > "$out/pass$i.log" 2>&1 || { echo "pass $i failed"; tail -5 "$out/pass$i.log"; exit 1; }
+  timeout -s KILL 300 rocprofv3 --pmc $pmc --output-format csv -d "$out/pass$i" -- python3 $root/bench.py --no-cpu-baseline --no-secondary --profile-min-paths 1 --steps 1 --warmup 0 "$@" > "$out/pass$i.log" 2>&1 || { echo "pass $i failed"; tail -5 "$out/pass$i.log"; exit 1; }
   echo "pass $i ok"
 done
