@@ -343,10 +343,13 @@ int  ptc_probe_segments(ptc_context* ctx, uint32_t n, const PtcSegmentProbe* in,
 int  ptc_eval_shading(ptc_context* ctx, int fn, uint32_t n, const float* in16, float* out4);
 
 /* The raw device counters of the PTC_OPT_COUNT_TRAVERSAL instantiations since the last ptc_reset_stats
- * (up to 24 words): [0..3] nodes visited / primitives tested by extension and shadow rays, [4] shadow rays,
+ * (up to 40 words): [0..3] nodes visited / primitives tested by extension and shadow rays, [4] shadow rays,
  * [8..14] extension and [16..22] shadow rays in the kernel with deferred tests, per wave summed over the
  * launch: loop iterations; lanes owning a ray, visiting a node, standing at a leaf in them; full batches of
- * 64 tests; partial batches and the tests in them. */
+ * 64 tests; partial batches and the tests in them.  [24..29] extension and [32..37] shadow rays, same kernel,
+ * over the loop iterations in which some lane visits a node: distinct nodes visited by the lanes of the wave;
+ * iterations in which all visiting lanes are at ONE node, and the lanes in them; iterations with at most four
+ * distinct nodes, and the lanes in them; lanes at the node most lanes of the wave share. */
 int  ptc_debug_counters(ptc_context* ctx, uint64_t* out, uint32_t n);
 /* Copies of the hierarchy ptc_build made on the device, in the node formats ptc_collapse_wide documents: the
  * two-child nodes and the four-wide nodes (which == 0: the hierarchy of the closest-hit rays, 1: of the any-hit

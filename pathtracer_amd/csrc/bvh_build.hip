@@ -1192,6 +1192,8 @@ std::string bvh_build(hipStream_t s, const BvhBuildInput& in, BvhBuildOutput& ou
     } else if (entries.size() == 2) {
         setChild(top[0], 0, entries[0]);
         setChild(top[0], 1, entries[1]);
+        // triangles in one entry, all (one or two) spheres in the other: the spheres can be tested up front
+        if (S >= 1 && S <= 2 && kt.n_big == 0 && REF_KIND(entries[1].ref) == REF_SPHERE && REF_COUNT(entries[1].ref) == S) out.root_without_spheres = entries[0].ref;
     } else if (entries.size() == 3) {
         setChild(top[1], 0, entries[1]);
         setChild(top[1], 1, entries[2]);

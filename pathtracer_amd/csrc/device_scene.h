@@ -104,6 +104,9 @@ struct DevScene {
     const WideNode* wnodes;     // the same hierarchy with four children per node; null when not built
     uint32_t n_tris, n_spheres, n_nodes, n_wnodes;
     uint32_t n_materials;       // entries of `materials`
+    // not REF_EMPTY_WORD: the one-ray-per-round kernels test every sphere (one or two) for every ray up front and start the
+    // traversal at this reference, the part of the hierarchy that holds everything else
+    uint32_t spheres_first_root;
     // lights
     const PtcPointLight* plights;
     const PtcDirectionalLight* dlights;

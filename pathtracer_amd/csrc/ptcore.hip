@@ -349,6 +349,7 @@ DevScene deviceScene(const ptc_context* c) {
     sc.n_plights = (uint32_t)c->plights.size();
     sc.n_dlights = (uint32_t)c->dlights.size();
     sc.n_qlights = (uint32_t)c->qlights.size();
+    sc.spheres_first_root = c->bvh.root_without_spheres;
     return sc;
 }
 
@@ -368,6 +369,7 @@ DevScene deviceSceneAny(const ptc_context* c) {
     sc.wnodes = c->bvh_any.wnodes;
     sc.n_wnodes = c->bvh_any.n_wnodes;
     sc.n_nodes = c->bvh_any.n_nodes;
+    sc.spheres_first_root = c->bvh_any.root_without_spheres;
     return sc;
 }
 
@@ -419,7 +421,7 @@ int uploadLights(ptc_context* ctx) {
 }
 
 #define TWO_TREES_MAX_PRIMS (1u << 19)  /* builder 3 above this size: one PLOC hierarchy */
-#define N_COUNTERS 24  /* [0..3] nodes / primitives (extension, shadow), [4] shadow rays, [5..6] maxima, [7] shadow rays found occluded (deferred kernel), [8..14] / [16..22] schedule statistics of the deferred kernel */
+#define N_COUNTERS 40  /* [0..3] nodes / primitives (extension, shadow), [4] shadow rays, [5..6] maxima, [7] shadow rays found occluded (deferred kernel), [8..14] / [16..22] schedule statistics of the deferred kernel, [24..29] / [32..37] how many lanes of a wave visit the same node */
 #define N_QCOUNT 20
 
 // Trace every bounce of the count0 paths k_generate left in the path state.  Per bounce:

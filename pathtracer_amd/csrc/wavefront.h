@@ -77,6 +77,9 @@ struct BvhBuildOutput {  // device allocations owned by the caller afterwards
     // box of the primitives that went into the trees (without the few "large" ones, e.g. a ground plane a
     // thousand times the size of everything else): the grid the ray-sort keys are taken on
     float sort_lo[3] = {0.f, 0.f, 0.f}, sort_hi[3] = {1.f, 1.f, 1.f};
+    // A scene with one or two spheres beside its triangles (the Cornell boxes): the reference of the rest of the
+    // hierarchy, so that every ray can test the spheres first and then traverse without them; REF_EMPTY_WORD otherwise.
+    uint32_t root_without_spheres = REF_EMPTY_WORD;
     double host_ms = 0.0;        // wall-clock time of the build's passes over primitives / nodes that ran in host code
 };
 

@@ -436,7 +436,7 @@ __device__ __forceinline__ DevScene scene_in_lds(const DevScene& sc, uint4* __re
 
 // Closest hit of the live paths, i.e. of entries [0, count) of the path state: hit_t / hit_ref
 // at the same position.
-template <bool COUNT, bool LDS = false>
+template <bool COUNT, bool LDS = false, bool SPHERES_FIRST = false>
 __global__ __launch_bounds__(BLOCK) void k_extend(RenderParams rp, DevScene sc_global, PathState ps, uint32_t count,
                                                   uint32_t* __restrict__ work_counter, uint32_t wave_chunk, unsigned long long* __restrict__ trav_counters) {
     constexpr int NS = LDS ? LDS_SCENE_STACK : TRAV_LDS_STACK;
@@ -464,6 +464,13 @@ __global__ __launch_bounds__(BLOCK) void k_extend(RenderParams rp, DevScene sc_g
                 if (!active) {  // NaN direction or empty scene: a miss
                     ps.hit_t[p] = best.t;
                     ps.hit_ref[p] = HIT_MISS;
+                } else if (SPHERES_FIRST) {
+                    // the scene's one or two spheres for every new ray, all lanes together (as a leaf of the hierarchy they are
+                    // reached by some lanes of the wave at a time, and the sphere test is the longest code of the loop); the
+                    // closest hit is the minimum over all accepted tests, in any order
+                    for (uint32_t k = 0; k < sc.n_spheres; ++k) accept_sphere(sc, k, r.o, r.d, r.tmin, r.tmax, best);
+                    if (COUNT) cnt.prims += sc.n_spheres;
+                    cur = sc.spheres_first_root;
                 }
             }
         }
@@ -633,6 +640,8 @@ __global__ __launch_bounds__(BLOCK, DQ_MIN_WAVES) void k_trace_deferred(RenderPa
     // COUNT only, wave-uniform: loop iterations, lanes that own a ray / visit a node / are at a leaf in them,
     // full and partial batches of primitive tests, items in the partial ones
     uint32_t st_iters = 0, st_owned = 0, st_node = 0, st_leaf = 0, st_full = 0, st_part = 0, st_part_items = 0;
+    // COUNT only: how coherent the node visits of the wave are (see ptc_debug_counters)
+    uint32_t sh_distinct = 0, sh_one_iters = 0, sh_one_lanes = 0, sh_four_iters = 0, sh_four_lanes = 0, sh_top_lanes = 0;
     for (;;) {
         // ---- retire finished rays, fetch new ones
         const bool fin = active && cur == REF_DONE;
@@ -734,6 +743,30 @@ __global__ __launch_bounds__(BLOCK, DQ_MIN_WAVES) void k_trace_deferred(RenderPa
             st_iters++;
             st_owned += (uint32_t)__popcll(__ballot(active));
             st_node += (uint32_t)__popcll(__ballot(do_node));
+            const unsigned long long visiting = __ballot(do_node);
+            unsigned long long left = visiting;
+            uint32_t distinct = 0, top = 0;
+            while (left) {  // one round per distinct node among the visiting lanes
+                const int l = __ffsll((long long)left) - 1;
+                const uint32_t v = (uint32_t)__shfl((int)cur, l);
+                const unsigned long long same = __ballot(do_node && cur == v);
+                ++distinct;
+                top = max(top, (uint32_t)__popcll(same));
+                left &= ~same;
+            }
+            if (visiting) {
+                const uint32_t lanes = (uint32_t)__popcll(visiting);
+                sh_distinct += distinct;
+                sh_top_lanes += top;
+                if (distinct == 1u) {
+                    sh_one_iters++;
+                    sh_one_lanes += lanes;
+                }
+                if (distinct <= 4u) {
+                    sh_four_iters++;
+                    sh_four_lanes += lanes;
+                }
+            }
         }
         // ---- ... then descend (the closest distance includes the tests just made)
         if (do_node) {
@@ -786,6 +819,13 @@ __global__ __launch_bounds__(BLOCK, DQ_MIN_WAVES) void k_trace_deferred(RenderPa
             atomicAdd(&st[4], (unsigned long long)st_full);
             atomicAdd(&st[5], (unsigned long long)st_part);
             atomicAdd(&st[6], (unsigned long long)st_part_items);
+            unsigned long long* sh = trav_counters + (ANY ? 32 : 24);
+            atomicAdd(&sh[0], (unsigned long long)sh_distinct);
+            atomicAdd(&sh[1], (unsigned long long)sh_one_iters);
+            atomicAdd(&sh[2], (unsigned long long)sh_one_lanes);
+            atomicAdd(&sh[3], (unsigned long long)sh_four_iters);
+            atomicAdd(&sh[4], (unsigned long long)sh_four_lanes);
+            atomicAdd(&sh[5], (unsigned long long)sh_top_lanes);
         }
     }
 }
@@ -1009,7 +1049,7 @@ __device__ __forceinline__ vec3 light_sample(const RenderParams& rp, const DevSc
 
 // ------------------------------------------------------------------ shadow --
 // Any-hit traversal of the queued shadow rays, same work distribution as k_extend.
-template <bool COUNT, bool LDS = false>
+template <bool COUNT, bool LDS = false, bool SPHERES_FIRST = false>
 __global__ __launch_bounds__(BLOCK) void k_shadow(RenderParams rp, DevScene sc_global, PathState ps, const uint32_t* __restrict__ count_ptr,
                                                   uint32_t* __restrict__ work_counter, uint32_t wave_chunk, unsigned long long* __restrict__ trav_counters,
                                                   unsigned long long* __restrict__ shadow_total) {
@@ -1036,6 +1076,16 @@ __global__ __launch_bounds__(BLOCK) void k_shadow(RenderParams rp, DevScene sc_g
                 const float4 o4 = ps.sh_o[idx], d4 = ps.sh_d[idx];
                 slot = f2u(d4.w);
                 active = trav_init(sc, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), rp.cf.epsilon, o4.w, r, sp, cur, best);
+                if (SPHERES_FIRST && active) {  // see k_extend
+                    bool blocked = false;
+                    for (uint32_t k = 0; k < sc.n_spheres; ++k) blocked = blocked || any_sphere(sc, k, r.o, r.d, r.tmin, r.tmax);
+                    if (COUNT) cnt.prims += sc.n_spheres;
+                    if (blocked) {
+                        contrib_store(ps, slot, mk3(0.f));
+                        active = false;
+                    }
+                    cur = sc.spheres_first_root;
+                }
             }
         }
         if (!__any(active)) {
@@ -1836,6 +1886,11 @@ static bool scene_fits_lds(const DevScene& sc) {
     return !LDS_SCENE_OFF && sc.n_nodes != 0u && sc.n_nodes <= LDS_SCENE_NODES && sc.nodes != nullptr && lds_scene_bytes(sc) <= LDS_SCENE_BYTES;
 }
 
+#ifndef SPHERES_FIRST_OFF
+#define SPHERES_FIRST_OFF 0
+#endif
+static bool spheres_first(const DevScene& sc) { return !SPHERES_FIRST_OFF && sc.spheres_first_root != REF_EMPTY_WORD && sc.n_spheres >= 1u && sc.n_spheres <= 2u; }
+
 static uint32_t auto_mode(const DevScene& sc, bool shadow) {
     if (sc.n_nodes > TINY_BVH_NODES) return 6u;
     if (scene_fits_lds(sc)) return (!shadow && sc.n_nodes <= STATIC_EXT_NODES) ? 0u : 1u;
@@ -1874,6 +1929,8 @@ void wf_extend(hipStream_t s, const RenderParams& rp, const DevScene& sc, const 
         hipLaunchKernelGGL(k_extend_static<false>, dim3(blocks_for(count)), dim3(BLOCK), 0, s, rp, sc, ps, count, trav_counters);
     else if (count_trav)
         hipLaunchKernelGGL(k_extend<true>, dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, count, work_counter, wave_chunk, trav_counters);
+    else if (scene_fits_lds(sc) && spheres_first(sc))
+        hipLaunchKernelGGL((k_extend<false, true, true>), dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, count, work_counter, wave_chunk, trav_counters);
     else if (scene_fits_lds(sc))
         hipLaunchKernelGGL((k_extend<false, true>), dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, count, work_counter, wave_chunk, trav_counters);
     else
@@ -1906,6 +1963,8 @@ void wf_shadow(hipStream_t s, const RenderParams& rp, const DevScene& sc, const 
         hipLaunchKernelGGL(k_shadow_static<false>, dim3(blocks_for(max_rays)), dim3(BLOCK), 0, s, rp, sc, ps, count_ptr, trav_counters, shadow_total);
     else if (count_trav)
         hipLaunchKernelGGL(k_shadow<true>, dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, count_ptr, work_counter, wave_chunk, trav_counters, shadow_total);
+    else if (scene_fits_lds(sc) && spheres_first(sc))
+        hipLaunchKernelGGL((k_shadow<false, true, true>), dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, count_ptr, work_counter, wave_chunk, trav_counters, shadow_total);
     else if (scene_fits_lds(sc))
         hipLaunchKernelGGL((k_shadow<false, true>), dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, count_ptr, work_counter, wave_chunk, trav_counters, shadow_total);
     else
