@@ -4,13 +4,13 @@
 root=$PWD
 export TMPDIR=/tmp
 cd /tmp
-rm -rf /tmp/tl && timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -- python3 $root/bench.py --steps 1 --warmup 1 --no-cpu-baseline "$@" > $root/gpurun_out/timeline.log 2>&1 || { tail -5 $root/gpurun_out/timeline.log; exit 1; }
+rm -rf /tmp/tl && timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -- python3 $root/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary "$@" > $root/gpurun_out/timeline.log 2>&1 || { tail -5 $root/gpurun_out/timeline.log; exit 1; }
 python3 - $root/gpurun_out/timeline.txt <<'PY'
 import csv, glob, sys
 rows = []
 for f in glob.glob('/tmp/tl/**/*kernel_trace.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0][:44], r.get('Queue_Id', '?'), r.get('Stream_Id', '?')))
+        rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0][:44], r.get('Queue_Id', '?'), r.get('Stream_Id', '?')))
 rows.sort()
 gen = [i for i, r in enumerate(rows) if r[2].startswith('k_generate')]
 rows = rows[gen[-1]:]   # the last batch

@@ -21,7 +21,7 @@ def main():
     for s in stats:
         for r in csv.DictReader(open(s)):
             name = r["Name"]
-            short = name.split("(")[0].replace("void ", "")
+            short = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
             if len(short) > 70:
                 short = short[:67] + "..."
             v = res.get(name, ("?",) * 5)
