@@ -6,7 +6,7 @@ set -e
 tag=$1
 o=gpurun_out/$tag
 mkdir -p $o
-cp $o/pmc_counters.json pmc_counters.json
+# (the top-level pmc_counters.json holds the first half's entries: gpurun_out/ does not travel to the box)
 ./tools/pmc_workloads.sh $tag cornell cornell_ggx sphere dragon_4k
 ./tools/diag/timeline.sh > /dev/null && cp gpurun_out/timeline.txt $o/dragon_timeline.txt
 ./tools/diag/timeline.sh --workload cornell_ggx > /dev/null && cp gpurun_out/timeline.txt $o/cornell_ggx_timeline.txt
