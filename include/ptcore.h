@@ -200,10 +200,12 @@ enum {
      * primitives of a kind always get 2 (a handful of nodes: host code is quicker than the launches), and
      * no "large primitive" leaf: in a Cornell box every wall is as large as the scene. */
     PTC_OPT_BVH_BUILDER = 10,
-    /* 1 (default) = when a scene mixes shading classes (triangle / sphere hits, Phong / GGX
-     * materials) the hits of a bounce are grouped by class before the surface kernel runs,
-     * so that the lanes of a wave take the same branches; 0 = plain path order. Results do
-     * not depend on it. */
+    /* 1 = when a scene mixes shading classes (triangle / sphere hits, Phong / GGX materials) the hits of a
+     * bounce are grouped by class before the surface kernel runs, so that the lanes of a wave take the same
+     * branches; 0 (default) = plain path order.  Results do not depend on it.  (Grouping paid while the surface
+     * kernel was bound by its arithmetic; now that it is bound by memory traffic on the small scenes, the scattered
+     * reads through the grouped queue cost more than the divergence: Cornell box with a GGX sphere 368 -> 336 ms
+     * per frame without it, the dragon and the Phong Cornell box +0.6 % / +1.3 %.) */
     PTC_OPT_GROUP_HITS = 11,
     /* 1 (default) = the kernel that adds a bounce's light terms to the path radiance runs
      * on a second stream of the context, beside the next bounce's extension traversal

@@ -73,7 +73,7 @@ struct ptc_context {
     std::vector<PtcDirectionalLight> dlights;
     std::vector<PtcQuadLight> qlights;
     bool non_diffuse = false;
-    bool group_hits = true;                     // PTC_OPT_GROUP_HITS
+    bool group_hits = false;                    // PTC_OPT_GROUP_HITS
     bool mixed_hits = false;                    // hits fall into more than one shading class (primitive kind x BRDF)
 
     // device scene
