@@ -74,6 +74,8 @@ struct ptc_context {
     std::vector<PtcQuadLight> qlights;
     bool non_diffuse = false;
     bool group_hits = false;                    // PTC_OPT_GROUP_HITS
+    bool dense_surface = true;                  // PTC_OPT_DENSE_SURFACE
+    float hit_ratio[16] = {0.f};                // hits per live path in the last batch: [0] camera rays, [b + 1] bounce b of later segments (0 = not known yet)
     bool mixed_hits = false;                    // hits fall into more than one shading class (primitive kind x BRDF)
 
     // device scene
@@ -423,6 +425,7 @@ int uploadLights(ptc_context* ctx) {
 #define TWO_TREES_MAX_PRIMS (1u << 19)  /* builder 3 above this size: one PLOC hierarchy */
 #define N_COUNTERS 40  /* [0..3] nodes / primitives (extension, shadow), [4] shadow rays, [5..6] maxima, [7] shadow rays found occluded (deferred kernel), [8..14] / [16..22] schedule statistics of the deferred kernel, [24..29] / [32..37] how many lanes of a wave visit the same node */
 #define N_QCOUNT 20
+#define DENSE_HIT_RATIO 0.95f  /* expected hits per live path from which on the hit compaction is skipped */
 
 // Trace every bounce of the count0 paths k_generate left in the path state.  Per bounce:
 // extend, hit compaction, surface (light samples + shadow rays, next direction,
@@ -478,7 +481,14 @@ int runBounces(ptc_context* ctx, const RenderParams& rp_frame, const DevScene& s
             ctx->stats.extend_timed_rays += count;
             ctx->stats.extend_timed_launches++;
         }
-        {
+        // Nearly every path of this bounce is expected to hit (the ratio of the bounce before it, or of the last batch's
+        // camera rays): no compaction pass, the surface kernel looks at all live paths and ends the misses itself.
+        // (the ratio this bounce had in the last batch: the camera rays of the dragon nearly all hit, the rays they spawn do not)
+        const bool camera = bounce == 0 && first_is_camera;
+        const uint32_t slot = camera ? 0u : std::min<uint32_t>(bounce + 1u, 15u);
+        const float expect = ctx->hit_ratio[slot];
+        const bool dense = ctx->dense_surface && !rp.group_hits && !rp.brute_force && wf_surface_can_skip_queue(rp) && expect >= DENSE_HIT_RATIO;
+        if (!dense) {
             Timed t(ctx, 3, nullptr, timed);
             wf_compact_hits(ctx->stream, rp, sc, ctx->ps, count, ctx->hitq, grp);
         }
@@ -488,8 +498,8 @@ int runBounces(ptc_context* ctx, const RenderParams& rp_frame, const DevScene& s
         }
         {
             Timed t(ctx, 2, nullptr, timed);
-            wf_surface(ctx->stream, rp, sc, ctx->ps, ctx->hitq, grp, count, ctx->npix_pad, sample_begin, ctx->segctr, grp + 1, ctx->gatherq,
-                       grp + 5, grp + 2, bounce == 0 && first_is_camera);
+            wf_surface(ctx->stream, rp, sc, ctx->ps, dense ? nullptr : ctx->hitq, grp, count, ctx->npix_pad, sample_begin, ctx->segctr, grp + 1, ctx->gatherq,
+                       grp + 5, grp + 2, bounce == 0 && first_is_camera, ctx->hitq /* unused as a queue then */);
         }
         if (S) {
             {
@@ -516,6 +526,7 @@ int runBounces(ptc_context* ctx, const RenderParams& rp_frame, const DevScene& s
         CHK(hipStreamSynchronize(ctx->stream));
         CHK(hipGetLastError());
         ctx->stats.surface_hits += ctx->h_count[0];
+        if (max_iters == 0xFFFFFFFFu) ctx->hit_ratio[slot] = (float)ctx->h_count[0] / (float)count;
         if (timed) {
             ctx->stats.surface_timed_hits += ctx->h_count[0];
             ctx->stats.surface_timed_launches++;
@@ -903,6 +914,7 @@ int ptc_build(ptc_context* ctx) try {
     ctx->stats.build_host_ms = ctx->bvh.host_ms + ctx->bvh_any.host_ms;
     ctx->stats.bvh_nodes = ctx->bvh.n_nodes;
     ctx->stats.bvh_max_depth = ctx->bvh.max_depth;
+    for (float& r : ctx->hit_ratio) r = 0.f;  // a new scene: nothing is known about its rays
     ctx->built = true;
     return PTC_OK;
 } catch (const std::exception& e) {
@@ -1260,6 +1272,7 @@ int ptc_set_option(ptc_context* ctx, int option, int64_t value) try {
         case PTC_OPT_GROUP_HITS: ctx->group_hits = value != 0; break;
         case PTC_OPT_OVERLAP_GATHER: ctx->overlap_gather = value != 0; break;
         case PTC_OPT_SORT_RAYS: ctx->sort_rays = value != 0; break;
+        case PTC_OPT_DENSE_SURFACE: ctx->dense_surface = value != 0; break;
         case PTC_OPT_BVH_BUILDER:
             if (value < 0 || value > 4) return fail(ctx, PTC_ERR_INVALID, "BVH builder must be 0 (LBVH), 1 (PLOC), 2 (surface-area sweep on the host), 4 (the same sweep on the GPU) or 3 (4 for closest-hit rays, 1 for any-hit rays)");
             ctx->bvh_builder = (int)value;

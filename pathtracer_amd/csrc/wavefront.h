@@ -23,9 +23,14 @@ void wf_compact_hits(hipStream_t s, const RenderParams& rp, const DevScene& sc, 
 // next direction / throughput, survivors -> the `*_next` path state, packed; segments whose radiance needs the
 // light terms -> gather_queue.
 // surface / shadow / gather read their queue length from device memory; `max_*` sizes the grid
-void wf_surface(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, const uint32_t* count_ptr,
+// `queue` == nullptr: no hit queue -- the kernel looks at all `max_count` live paths, ends the ones that missed itself and
+// adds the number of hits to *count_ptr (which must be zero before) by way of `block_tally`, a scratch array of one word per
+// block of the launch (at least max_count / 256 + 1 words); only where wf_surface_can_skip_queue().
+bool wf_surface_can_skip_queue(const RenderParams& rp);
+void wf_surface(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, uint32_t* count_ptr,
                 uint32_t max_count, uint32_t npix_pad, uint32_t sample_begin, uint32_t* segctr, uint32_t* next_count,
-                uint32_t* gather_queue, uint32_t* gather_count, uint32_t* shadow_count, bool first_bounce /* camera segments: throughput 1 is implied */);
+                uint32_t* gather_queue, uint32_t* gather_count, uint32_t* shadow_count, bool first_bounce /* camera segments: throughput 1 is implied */,
+                uint32_t* block_tally);
 void wf_shadow(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* count_ptr, uint64_t max_rays,
                uint32_t* work_counter, uint32_t resident_waves, bool count_trav, unsigned long long* trav_counters, unsigned long long* shadow_total);
 void wf_gather(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* gather_queue, const uint32_t* gather_count,

@@ -203,12 +203,13 @@ struct Reserve4 {
     uint32_t base, first;               // threads 0..2: the block's first position on their counter; thread 0: entries of stream 0
 };
 struct Reserve4Lds {
-    uint32_t cnt[16][4];
+    uint32_t cnt[16][5];
     uint32_t base[4];
 };
 
+// `tally` / `c_tally` (optional): a fifth count of which only the block's total is wanted: written to c_tally[blockIdx.x].
 __device__ __forceinline__ void reserve4_begin(Reserve4& r, Reserve4Lds& L, bool k0, bool k1, bool k2, bool k3, uint32_t* __restrict__ c01, uint32_t* __restrict__ c2,
-                                               uint32_t* __restrict__ c3) {
+                                               uint32_t* __restrict__ c3, bool tally = false, uint32_t* __restrict__ c_tally = nullptr) {
     const uint32_t lane = __lane_id();
     const uint32_t wave = threadIdx.x >> 6, nwaves = (blockDim.x + 63u) >> 6;
     r.m0 = __ballot(k0);
@@ -222,7 +223,16 @@ __device__ __forceinline__ void reserve4_begin(Reserve4& r, Reserve4Lds& L, bool
         L.cnt[wave][2] = (uint32_t)__popcll(r.m2);
         L.cnt[wave][3] = (uint32_t)__popcll(r.m3);
     }
+    if (c_tally) {
+        const unsigned long long m4 = __ballot(tally);
+        if (lane == 0) L.cnt[wave][4] = (uint32_t)__popcll(m4);
+    }
     __syncthreads();
+    if (c_tally && threadIdx.x == 3u) {  // a plain store per block (summed by k_sum_words afterwards): a second atomic request per block would cost as much as the first
+        uint32_t t = 0;
+        for (uint32_t w = 0; w < nwaves; ++w) t += L.cnt[w][4];
+        c_tally[blockIdx.x] = t;
+    }
     if (threadIdx.x < 3u) {
         uint32_t t0 = 0, t1 = 0;
         const uint32_t k = threadIdx.x == 0u ? 0u : threadIdx.x + 1u;
@@ -1505,8 +1515,12 @@ __global__ __launch_bounds__(SURF_BLOCK_MANY, SURF_WAVES) void k_surface(RenderP
                                                        const uint32_t* __restrict__ count_ptr, uint32_t npix_pad, uint32_t sample_begin, uint32_t* __restrict__ segctr,
                                                        uint32_t* __restrict__ next_count,
                                                        uint32_t* __restrict__ gather_queue, uint32_t* __restrict__ gather_count,
-                                                       uint32_t* __restrict__ shadow_count, uint32_t first_bounce) {
-    const uint32_t count = *count_ptr;  // hits of this bounce, written by k_compact_hits
+                                                       uint32_t* __restrict__ shadow_count, uint32_t first_bounce, uint32_t dense_count, uint32_t* __restrict__ hit_tally) {
+    // queue == nullptr ("dense"): there is no hit queue; thread i looks at live path i of the bounce, which may have missed
+    // (then it does what the hit compaction does for a miss) and the block notes its hits in hit_tally[blockIdx.x].  Taken when nearly
+    // every path of the bounce is expected to hit: the compaction pass and the queue's 12 bytes per path are saved.
+    const bool dense = queue == nullptr;
+    const uint32_t count = dense ? dense_count : *count_ptr;  // hits of this bounce, written by k_compact_hits
     if (blockIdx.x * blockDim.x >= count) return;
     __shared__ uint32_t mat_copy[MATS ? MAT_LDS_MAX * MAT_WORDS : 1u];
     __shared__ uint32_t qlight_copy[MATS ? QLIGHT_LDS_MAX * QLIGHT_WORDS : 1u];
@@ -1520,15 +1534,21 @@ __global__ __launch_bounds__(SURF_BLOCK_MANY, SURF_WAVES) void k_surface(RenderP
         sc.qlights = reinterpret_cast<const PtcQuadLight*>(qlight_copy);
     }
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool hit = i < count;
+    bool hit = i < count;
     bool sample = false, alive = false, gather = false;
     uint32_t p = 0, bounce = 0;
     Segment sg;
     HitAttr at;
     uint32_t at_state = 0;  // position of the path's state
+    int hit_ref = HIT_MISS;
     float4 n_o = make_float4(0.f, 0.f, 0.f, 0.f), n_d = n_o, n_t = n_o;  // state of the next segment
+    const bool in_range = hit;
+    if (in_range) {
+        at_state = dense ? i : queue[i];
+        hit_ref = ps.hit_ref[at_state];
+        hit = hit_ref != HIT_MISS;  // (a queued path always hit)
+    }
     if (hit) {
-        at_state = queue[i];
         // camera segments: throughput 1 (k_generate does not write it), path number in an array of its own; later
         // segments carry the path number in the fourth word of their throughput record
         float4 o4, d4;
@@ -1548,8 +1568,18 @@ __global__ __launch_bounds__(SURF_BLOCK_MANY, SURF_WAVES) void k_surface(RenderP
         sg.depth = f2u(d4.w);
         sg.done = false;
         bounce = sg.depth;  // a live path has gained one unit of depth per segment (every integrator's survivors do `depth++` once)
-        hit_attributes(sc, ps.hit_ref[at_state], ps.hit_t[at_state], sg.o, sg.d, at);
+        hit_attributes(sc, hit_ref, ps.hit_t[at_state], sg.o, sg.d, at);
         sample = rp.samples_per_path != 0u && samples_lights<INTEG>(rp, at.mat, sg.depth);
+    }
+    if (in_range && !hit) {  // dense only: a miss ends the path: radiance = background colour (Common.cu:13-18), as k_compact_hits does
+        if (rp.init_L || rp.bg[0] != 0.f || rp.bg[1] != 0.f || rp.bg[2] != 0.f) {
+            const uint32_t pm = first_bounce ? ps.pid[at_state] : f2u(ps.thr[at_state].w);
+            float4 L = rp.init_L ? make_float4(0.f, 0.f, 0.f, 0.f) : ps.L[pm];
+            L.x += rp.bg[0];
+            L.y += rp.bg[1];
+            L.z += rp.bg[2];
+            ps.L[pm] = L;
+        }
     }
     if (MATS) __syncthreads();  // the material table is in place (the hit's own loads above were in flight beside the copy)
     // ---- the light samples: term + shadow ray each; a term that is exactly zero adds
@@ -1654,7 +1684,7 @@ __global__ __launch_bounds__(SURF_BLOCK_MANY, SURF_WAVES) void k_surface(RenderP
     // still, before the closest-hit program, costs a barrier in the middle of the kernel: +17 ms per frame.)
     __shared__ Reserve4Lds rs_lds;
     Reserve4 rs;
-    if (few) reserve4_begin(rs, rs_lds, f_need[0], f_need[1], gather, alive, shadow_count, gather_count, next_count);
+    if (few) reserve4_begin(rs, rs_lds, f_need[0], f_need[1], gather, alive, shadow_count, gather_count, next_count, hit, dense ? hit_tally : nullptr);
     if (alive) {
         uint32_t pix, x, y;
         uint32_t sample;
@@ -1998,16 +2028,33 @@ void wf_compact_hits(hipStream_t s, const RenderParams& rp, const DevScene& sc, 
 #endif
 
 // `count_ptr` (device) holds the number of queued paths; `max_count` bounds it and sizes the grid.
-void wf_surface(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, const uint32_t* count_ptr,
+bool wf_surface_can_skip_queue(const RenderParams& rp) { return rp.samples_per_path <= 2u; }
+
+// *total += the n words at `words`.
+__global__ __launch_bounds__(1024) void k_sum_words(const uint32_t* __restrict__ words, uint32_t n, uint32_t* __restrict__ total) {
+    __shared__ uint32_t part[16];
+    uint32_t sum = 0;
+    for (uint32_t k = blockIdx.x * 1024u + threadIdx.x; k < n; k += gridDim.x * 1024u) sum += words[k];
+    for (int off = 32; off > 0; off >>= 1) sum += (uint32_t)__shfl_down((int)sum, off);
+    if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        uint32_t t = 0;
+        for (int w = 0; w < 16; ++w) t += part[w];
+        if (t) atomicAdd(total, t);
+    }
+}
+
+void wf_surface(hipStream_t s, const RenderParams& rp, const DevScene& sc, const PathState& ps, const uint32_t* queue, uint32_t* count_ptr,
                 uint32_t max_count, uint32_t npix_pad, uint32_t sample_begin, uint32_t* segctr, uint32_t* next_count,
-                uint32_t* gather_queue, uint32_t* gather_count, uint32_t* shadow_count, bool first_bounce) {
+                uint32_t* gather_queue, uint32_t* gather_count, uint32_t* shadow_count, bool first_bounce, uint32_t* block_tally) {
     if (max_count == 0) return;
     const uint32_t block = rp.samples_per_path <= 2u ? SURF_BLOCK_FEW : SURF_BLOCK_MANY;
     const dim3 g(blocks_for(max_count, block)), b(block);
     const bool mats = !MAT_LDS_OFF && sc.n_materials != 0u && sc.n_materials <= MAT_LDS_MAX && sc.n_qlights <= QLIGHT_LDS_MAX;
 #define PT_SURFACE_LAUNCH(I, M, F)                                                                                                                            \
     hipLaunchKernelGGL((k_surface<I, M, F>), g, b, 0, s, rp, sc, ps, queue, count_ptr, npix_pad, sample_begin, segctr, next_count, gather_queue, gather_count, \
-                       shadow_count, first_bounce ? 1u : 0u)
+                       shadow_count, first_bounce ? 1u : 0u, max_count, block_tally)
 #define PT_SURFACE(I)                           \
     do {                                        \
         if (mats) PT_SURFACE_LAUNCH(I, true, false);  \
@@ -2030,6 +2077,10 @@ void wf_surface(hipStream_t s, const RenderParams& rp, const DevScene& sc, const
     }
 #undef PT_SURFACE_LAUNCH
 #undef PT_SURFACE
+    if (!queue) {  // the blocks' hit counts -> *count_ptr
+        const uint32_t nb = blocks_for(max_count, block);
+        hipLaunchKernelGGL(k_sum_words, dim3(std::min<uint32_t>(blocks_for(nb, 1024u), 256u)), dim3(1024), 0, s, block_tally, nb, count_ptr);
+    }
 }
 
 // `gather_count` (device) holds the number of queued paths; `max_count` bounds it and sizes the grid.

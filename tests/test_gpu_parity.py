@@ -381,6 +381,32 @@ def test_hit_grouping_does_not_change_results(rel, over):
 
 
 @pytest.mark.parametrize("rel,over", [("scene4/dragon.test", dict(size="320 240", spp="8")), ("scene3/cornellRR.test", dict(size="96 96", spp="16")),
+                                      ("scene4/ggx.test", dict(size="320 70", spp="8")), ("scene4/cornellBRDF.test", dict(size="128 128", spp="16", maxdepth="6"))])
+@pytest.mark.parametrize("seeding", [1, 0])
+def test_skipping_the_hit_compaction_does_not_change_results(rel, over, seeding):
+    """Bounces whose paths nearly all hit something (closed boxes; decided from the bounce before) go without the hit
+    queue -- the surface kernel looks at every live path and ends the misses itself -- or with it: bit-identical sums
+    and the same ray and hit counts; several frames in a row so that the camera rays' decision (taken from the previous
+    batch) is exercised both ways."""
+    scene = load(rel, **over)
+    out = []
+    for dense in (0, 1):
+        r = Renderer(scene, options={_ffi.OPT_SEMANTICS: 1, _ffi.OPT_SEEDING: seeding, _ffi.OPT_BOUNCE_CAP: 8, _ffi.OPT_DENSE_SURFACE: dense})
+        frames = []
+        for _ in range(3):
+            r.reset_stats()
+            r.render_range(0, scene.samples_per_pixel, clear=True)
+            st = r.stats()
+            frames.append((r.sums().copy(), st.extension_rays, st.shadow_rays, st.surface_hits))
+        r.close()
+        for f in frames[1:]:
+            assert np.array_equal(frames[0][0].view(np.uint32), f[0].view(np.uint32)) and frames[0][1:] == f[1:]
+        out.append(frames[0])
+    assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
+    assert out[0][1:] == out[1][1:]
+
+
+@pytest.mark.parametrize("rel,over", [("scene4/dragon.test", dict(size="320 240", spp="8")), ("scene3/cornellRR.test", dict(size="96 96", spp="16")),
                                       ("scene2/sphere.test", dict(size="160 120"))])
 def test_gather_on_second_stream_does_not_change_results(rel, over):
     """The radiance gather of a bounce beside the next bounce's traversal (second stream, two
