@@ -164,7 +164,7 @@ enum {
     PTC_OPT_CULL_ZERO = 4,
     /* Maximum camera paths in flight per wavefront batch (rounded to whole samples over
      * the image, and limited to what fits in half of the free device memory at about
-     * 170 + 44 x light samples bytes per path). Default 536870912 (about 140 GB with two
+     * 152 + 44 x light samples bytes per path). Default 536870912 (about 140 GB with two
      * light samples per segment): fewer, larger launches per frame.  A batch holds fewer
      * than 2^30 paths whatever is asked for. */
     PTC_OPT_BATCH_PATHS = 5,
