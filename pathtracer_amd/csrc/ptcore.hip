@@ -13,6 +13,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstring>
+#include <thread>
 #include <map>
 #include <mutex>
 #include <string>
@@ -425,7 +426,9 @@ int uploadLights(ptc_context* ctx) {
 #define TWO_TREES_MAX_PRIMS (1u << 19)  /* builder 3 above this size: one PLOC hierarchy */
 #define N_COUNTERS 40  /* [0..3] nodes / primitives (extension, shadow), [4] shadow rays, [5..6] maxima, [7] shadow rays found occluded (deferred kernel), [8..14] / [16..22] schedule statistics of the deferred kernel, [24..29] / [32..37] how many lanes of a wave visit the same node */
 #define N_QCOUNT 20
+#ifndef DENSE_HIT_RATIO
 #define DENSE_HIT_RATIO 0.95f  /* expected hits per live path from which on the hit compaction is skipped */
+#endif
 
 // Trace every bounce of the count0 paths k_generate left in the path state.  Per bounce:
 // extend, hit compaction, surface (light samples + shadow rays, next direction,
@@ -839,16 +842,24 @@ int ptc_build(ptc_context* ctx) try {
     std::map<std::string, uint32_t> ids;
     std::vector<PtcMaterialValue> mats;
     ctx->non_diffuse = false;
+    const PtcMaterialValue* last_mv = nullptr;  // a mesh's primitives come in runs of one material: compare with the previous one first
+    uint32_t last_id = 0;
     auto matId = [&](const PtcMaterialValue& mv, int objType) {
-        std::string key((const char*)&mv, sizeof(mv));
-        auto it = ids.find(key);
         uint32_t id;
-        if (it == ids.end()) {
-            id = (uint32_t)mats.size();
-            ids.emplace(key, id);
-            mats.push_back(mv);
+        if (last_mv && memcmp(last_mv, &mv, sizeof(mv)) == 0) {
+            id = last_id;
         } else {
-            id = it->second;
+            std::string key((const char*)&mv, sizeof(mv));
+            auto it = ids.find(key);
+            if (it == ids.end()) {
+                id = (uint32_t)mats.size();
+                ids.emplace(key, id);
+                mats.push_back(mv);
+            } else {
+                id = it->second;
+            }
+            last_mv = &mv;
+            last_id = id;
         }
         if (mv.matType != PTC_DIFFUSE) ctx->non_diffuse = true;
         return id | (objType == PTC_LIGHT ? MAT_LIGHT_BIT : 0u);
@@ -885,20 +896,46 @@ int ptc_build(ptc_context* ctx) try {
     in.extra_extent = ctx->have_cfg ? std::max(fabsf(ctx->cfg.eye.x), std::max(fabsf(ctx->cfg.eye.y), fabsf(ctx->cfg.eye.z))) : 0.f;
     // A hierarchy the traversal stack cannot hold (clustering and sweep follow the geometry, and some geometry
     // makes chains) is built again as a radix tree over the Morton codes, whose depth is bounded by the key length.
-    auto build = [&](int builder, BvhBuildOutput& out) {
-        in.builder = builder;
-        std::string e = bvh_build(ctx->stream, in, out);
+    auto build = [&in](int builder, BvhBuildOutput& out, hipStream_t s) {
+        BvhBuildInput mine = in;
+        mine.builder = builder;
+        std::string e = bvh_build(s, mine, out);
         if (!e.empty() && builder != 0 && e.find("too deep") != std::string::npos) {
             bvh_free(out);
-            in.builder = 0;
-            e = bvh_build(ctx->stream, in, out);
+            mine.builder = 0;
+            e = bvh_build(s, mine, out);
         }
         return e;
     };
-    std::string err = build(in.builder, ctx->bvh);
-    if (err.empty() && two) {  // closest-hit rays: surface-area sweep (above); any-hit rays: clustering
-        err = build(1, ctx->bvh_any);
+    std::string err;
+    if (two) {
+        // closest-hit rays: surface-area sweep; any-hit rays: clustering.  A build is a chain of some 1500 short launches and
+        // a dozen read-backs of a few words, bound by launch and round-trip latency, not by the GPU: the two hierarchies are
+        // built side by side, the second from a host thread of its own on the context's second stream (which starts behind
+        // the uploads above).
+        CHK(hipEventRecord(ctx->ev_shadow, ctx->stream));
+        CHK(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_shadow, 0));
+        std::string err_any;
+        std::thread side([&] {
+            try {
+                if (hipSetDevice(ctx->device) != hipSuccess) err_any = "BVH build: hipSetDevice failed in the second build thread";
+                else err_any = build(1, ctx->bvh_any, ctx->aux_stream);
+            } catch (const std::exception& e) {
+                err_any = std::string("BVH build: ") + e.what();
+            }
+        });
+        try {
+            err = build(in.builder, ctx->bvh, ctx->stream);
+        } catch (...) {
+            side.join();
+            throw;
+        }
+        side.join();
+        (void)hipStreamSynchronize(ctx->aux_stream);
+        if (err.empty()) err = err_any;
         ctx->two_trees = err.empty();
+    } else {
+        err = build(in.builder, ctx->bvh, ctx->stream);
     }
     if (!err.empty()) {
         bvh_free(ctx->bvh);

@@ -1497,7 +1497,7 @@ __device__ __forceinline__ vec3 gather_radiance(const RenderParams& rp, const De
 #endif
 #define SURF_BLOCK_MANY 1024
 #ifndef SURF_WAVES
-#define SURF_WAVES 5   /* waves per SIMD the register allocation aims at */
+#define SURF_WAVES 6   /* waves per SIMD the register allocation aims at: 80 registers with 7 of them spilled beats 5 waves without spills by 1-1.5 % of the kernel's time (and beats 80 registers without spills, which the kernel gets when the shadow rays' common origin is not kept per sample: the schedule that comes out of that is 3 % slower); 7 waves (72 registers, 34 spilled) lose 25 %, 8 lose 100 % */
 #endif
 // One thread per path of the bounce that hit something.
 // MATS: the material table (at most MAT_LDS_MAX de-duplicated records: any scene whose primitives share a few materials,
