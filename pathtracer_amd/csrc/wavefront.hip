@@ -1489,15 +1489,39 @@ __device__ __forceinline__ vec3 gather_radiance(const RenderParams& rp, const De
 
 #define GATHER_WITH_LE 0x80000000u   /* bits of a segment's word in PathState::g_p beside the path number */
 #define GATHER_A_SET 0x40000000u
-// Threads per block of k_surface.  With one or two light samples per hit: 256 (measured 256 > 512 by
-// 1-3 % > 1024 by 4 % more >> 128).  With many samples per hit every sample takes one queue atomic
+// Threads per block of k_surface.  With one or two light samples per hit: 256 for small launches, 512 / 768 for large
+// ones (below).  With many samples per hit every sample takes one queue atomic
 // per block, and the rate of atomics on one word (about 88 per microsecond) bounds the kernel: 1024.
 #ifndef SURF_BLOCK_FEW
 #define SURF_BLOCK_FEW 256
 #endif
 #define SURF_BLOCK_MANY 1024
+// Large launches with one or two samples per hit: every block sends ONE request for its queue positions, all to the same
+// cache line, which takes about 88 requests per microsecond -- 2.1 M blocks of 256 threads (the first bounce of a 1080p x 256 spp
+// frame) are 24 ms of requests, and that was the kernel's whole time on three different workloads.  Blocks of 512 / 768 threads
+// (8 / 12 waves: three / two blocks fill the 24 wave slots of a CU; 384, 640 and 1024 threads do not divide them and lose 10-25 %)
+// halve / third the requests; the block barriers get dearer, so small launches stay at 256.  Which of the two is faster depends
+// on the work per hit: 768 with two light samples per hit (dragon: 95.8 -> 84.5 ms per three frames in this kernel; 512: 88.5),
+// 512 with one (Cornell box: 107.7 -> 82.9; 768: 86.5).  The instantiations with the correctly rounded arithmetic need their
+// registers (5 waves per SIMD, 20 wave slots per CU: 768 threads would leave 8 of them empty): 512 with one sample (Cornell box,
+// literal semantics: -20 % of the kernel's time against 256), 256 with two (dragon, literal: 96.7 ms; 512: 102.7; 768: 147).
+#ifndef SURF_BLOCK_BIG_ONE
+#define SURF_BLOCK_BIG_ONE 512
+#endif
+#ifndef SURF_BLOCK_BIG_TWO
+#define SURF_BLOCK_BIG_TWO 768
+#endif
+#ifndef SURF_BLOCK_BIG_TWO_EXACT
+#define SURF_BLOCK_BIG_TWO_EXACT 256
+#endif
+#ifndef SURF_BIG_LAUNCH
+#define SURF_BIG_LAUNCH (1u << 21)   /* hits from which on the larger blocks still fill the GPU several times over */
+#endif
 #ifndef SURF_WAVES
-#define SURF_WAVES 6   /* waves per SIMD the register allocation aims at: 80 registers with 7 of them spilled beats 5 waves without spills by 1-1.5 % of the kernel's time (and beats 80 registers without spills, which the kernel gets when the shadow rays' common origin is not kept per sample: the schedule that comes out of that is 3 % slower); 7 waves (72 registers, 34 spilled) lose 25 %, 8 lose 100 % */
+#define SURF_WAVES 6   /* waves per SIMD the register allocation aims at, hardware reciprocal / square root (FAST): 80 registers with 7 of them spilled beats 5 waves without spills by 1-1.5 % of the kernel's time (and beats 80 registers without spills, which the kernel gets when the shadow rays' common origin is not kept per sample: the schedule that comes out of that is 3 % slower); 7 waves (72 registers, 34 spilled) lose 25 %, 8 lose 100 % */
+#endif
+#ifndef SURF_WAVES_EXACT
+#define SURF_WAVES_EXACT 5   /* the same with the correctly rounded operations: at 6 waves the spills cost 30 % (dragon, literal semantics) */
 #endif
 // One thread per path of the bounce that hit something.
 // MATS: the material table (at most MAT_LDS_MAX de-duplicated records: any scene whose primitives share a few materials,
@@ -1511,7 +1535,7 @@ __device__ __forceinline__ vec3 gather_radiance(const RenderParams& rp, const De
 // FAST: the shading arithmetic takes the hardware's reciprocal / square root / reciprocal square root (ShMath); the
 // path tracer under `intended` semantics only.
 template <int INTEG, bool MATS = false, bool FAST = false>
-__global__ __launch_bounds__(SURF_BLOCK_MANY, SURF_WAVES) void k_surface(RenderParams rp, DevScene sc_global, PathState ps, const uint32_t* __restrict__ queue,
+__global__ __launch_bounds__(SURF_BLOCK_MANY, FAST ? SURF_WAVES : SURF_WAVES_EXACT) void k_surface(RenderParams rp, DevScene sc_global, PathState ps, const uint32_t* __restrict__ queue,
                                                        const uint32_t* __restrict__ count_ptr, uint32_t npix_pad, uint32_t sample_begin, uint32_t* __restrict__ segctr,
                                                        uint32_t* __restrict__ next_count,
                                                        uint32_t* __restrict__ gather_queue, uint32_t* __restrict__ gather_count,
@@ -2049,7 +2073,12 @@ void wf_surface(hipStream_t s, const RenderParams& rp, const DevScene& sc, const
                 uint32_t max_count, uint32_t npix_pad, uint32_t sample_begin, uint32_t* segctr, uint32_t* next_count,
                 uint32_t* gather_queue, uint32_t* gather_count, uint32_t* shadow_count, bool first_bounce, uint32_t* block_tally) {
     if (max_count == 0) return;
-    const uint32_t block = rp.samples_per_path <= 2u ? SURF_BLOCK_FEW : SURF_BLOCK_MANY;
+    // hardware reciprocal / square root in the shading arithmetic: the path tracer under `intended` semantics
+    // (`literal` keeps the correctly rounded operations: there a last bit decides between 1 and NaN)
+    const bool fast = PT_SHADING_FAST && rp.semantics == 1 && rp.integrator == INT_PATHTRACER;
+    const uint32_t block = rp.samples_per_path > 2u ? SURF_BLOCK_MANY
+                           : max_count < SURF_BIG_LAUNCH ? SURF_BLOCK_FEW
+                           : rp.samples_per_path == 2u ? (fast ? SURF_BLOCK_BIG_TWO : SURF_BLOCK_BIG_TWO_EXACT) : SURF_BLOCK_BIG_ONE;
     const dim3 g(blocks_for(max_count, block)), b(block);
     const bool mats = !MAT_LDS_OFF && sc.n_materials != 0u && sc.n_materials <= MAT_LDS_MAX && sc.n_qlights <= QLIGHT_LDS_MAX;
 #define PT_SURFACE_LAUNCH(I, M, F)                                                                                                                            \
@@ -2060,9 +2089,6 @@ void wf_surface(hipStream_t s, const RenderParams& rp, const DevScene& sc, const
         if (mats) PT_SURFACE_LAUNCH(I, true, false);  \
         else PT_SURFACE_LAUNCH(I, false, false);      \
     } while (0)
-    // hardware reciprocal / square root in the shading arithmetic: the path tracer under `intended` semantics
-    // (`literal` keeps the correctly rounded operations: there a last bit decides between 1 and NaN)
-    const bool fast = PT_SHADING_FAST && rp.semantics == 1;
     switch (rp.integrator) {
         case INT_RAYTRACER: PT_SURFACE(INT_RAYTRACER); break;
         case INT_ANALYTICDIRECT: PT_SURFACE(INT_ANALYTICDIRECT); break;
