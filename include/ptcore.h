@@ -224,7 +224,14 @@ enum {
      * the surface kernel then looks at every live path and ends the ones that missed itself.  Saves a kernel and 12
      * bytes of memory traffic per path in closed scenes.  Only with at most two light samples per hit and without
      * hit grouping.  0 = always compact.  Results do not depend on it. */
-    PTC_OPT_DENSE_SURFACE = 14
+    PTC_OPT_DENSE_SURFACE = 14,
+    /* 1 (default) = a scene's few very large triangles (a floor under a mesh: they sit in a leaf of their own under the
+     * root of the hierarchy, and every ray that starts on them is inside that leaf's box) are looked at once more where a
+     * ray is made: the surface kernel runs the first exits of the triangle test against their planes for the shadow rays
+     * and the next segment of every hit, and a ray that cannot hit any of them carries a mark with which the traversal
+     * kernels start below that leaf.  The exits are the triangle test's own, so the same hits are found; a quarter of
+     * the dragon's shadow-ray triangle tests go away.  0 = no ray is marked.  Results do not depend on it. */
+    PTC_OPT_MARK_RAYS = 15
 };
 
 /* ----------------------------------------------------------- entry points -- */

@@ -101,6 +101,7 @@ OPT_GROUP_HITS = 11
 OPT_OVERLAP_GATHER = 12
 OPT_SORT_RAYS = 13
 OPT_DENSE_SURFACE = 14
+OPT_MARK_RAYS = 15
 
 ERR_INVALID, ERR_INTEGRATOR, ERR_DEVICE, ERR_UNSUPPORTED, ERR_NOT_BUILT, ERR_HOST, ERR_NOMEM, ERR_BUSY = -1, -2, -3, -4, -5, -6, -7, -8
 

@@ -1194,6 +1194,13 @@ std::string bvh_build(hipStream_t s, const BvhBuildInput& in, BvhBuildOutput& ou
         setChild(top[0], 1, entries[1]);
         // triangles in one entry, all (one or two) spheres in the other: the spheres can be tested up front
         if (S >= 1 && S <= 2 && kt.n_big == 0 && REF_KIND(entries[1].ref) == REF_SPHERE && REF_COUNT(entries[1].ref) == S) out.root_without_spheres = entries[0].ref;
+        // a triangle tree and one leaf with the (at most three) large triangles: those can be plane-tested for every ray up front
+        if (S == 0 && kt.has_tree && kt.n_big >= 1 && kt.n_big <= 3 && entries[1].ref == MAKE_LEAF(REF_TRI, kt.n_small, kt.n_big)) {
+            out.big_first = kt.n_small;
+            out.big_count = kt.n_big;
+            for (uint32_t k = 0; k < kt.n_big; ++k) out.big_prim[k] = kt.slot_prim[kt.n_small + k];
+            out.root_without_big = entries[0].ref;
+        }
     } else if (entries.size() == 3) {
         setChild(top[1], 0, entries[1]);
         setChild(top[1], 1, entries[2]);
@@ -1256,7 +1263,7 @@ std::string bvh_build(hipStream_t s, const BvhBuildInput& in, BvhBuildOutput& ou
 #define WIDE_HOST_MAX_NODES 256u   /* hierarchies of a few nodes: the host loop is quicker than two launches per level */
 #endif
     if (out.n_nodes > WIDE_HOST_MAX_NODES) {
-        HIPCHK(hipMalloc((void**)&out.wnodes, (size_t)out.n_nodes * sizeof(WideNode)));
+        HIPCHK(hipMalloc((void**)&out.wnodes, ((size_t)out.n_nodes + 1u) * sizeof(WideNode)));  // + the root without the large triangles, below
         bool wide_ok = false;
         const std::string werr = wide_collapse_device(s, out.nodes, out.n_nodes, out.max_depth, MAKE_LEAF(REF_TRI, T, 1u), out.wnodes, out.n_wnodes, out.wide_depth, wide_ok);
         if (!werr.empty()) return werr;
@@ -1277,12 +1284,30 @@ std::string bvh_build(hipStream_t s, const BvhBuildInput& in, BvhBuildOutput& ou
             wide_ok = collapseWide(h_bin, h_wide, wdepth, MAKE_LEAF(REF_TRI, T, 1u));
         }
         if (wide_ok) {  // slot T: the degenerate triangle after the scene's
-            HIPCHK(hipMalloc((void**)&out.wnodes, h_wide.size() * sizeof(WideNode)));
+            HIPCHK(hipMalloc((void**)&out.wnodes, (h_wide.size() + 1u) * sizeof(WideNode)));
             HIPCHK(hipMemcpyAsync(out.wnodes, h_wide.data(), h_wide.size() * sizeof(WideNode), hipMemcpyHostToDevice, s));
             HIPCHK(hipStreamSynchronize(s));
             out.n_wnodes = (uint32_t)h_wide.size();
             out.wide_depth = wdepth;
         }
+    }
+    // 7. the four-wide root once more, after the hierarchy's own nodes, with the child slot of the large-triangle leaf emptied:
+    // where the kernels that test those triangles up front start
+    if (out.wnodes && out.big_count) {
+        WideNode root;
+        HIPCHK(hipMemcpyAsync(&root, out.wnodes, sizeof(root), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        const uint32_t leaf = MAKE_LEAF(REF_TRI, out.big_first, out.big_count);
+        for (int c = 0; c < 4; ++c)
+            if (root.child[c] == leaf) {  // a leaf child of the binary root is a child of the wide root (the collapse only opens internal children)
+                root.child[c] = MAKE_LEAF(REF_TRI, T, 1u);  // like every unused slot: an inside-out box, the all-zero triangle after the scene's
+                root.qlo_x[c] = root.qlo_y[c] = root.qlo_z[c] = 255;
+                root.qhi_x[c] = root.qhi_y[c] = root.qhi_z[c] = 0;
+                HIPCHK(hipMemcpyAsync(out.wnodes + out.n_wnodes, &root, sizeof(root), hipMemcpyHostToDevice, s));
+                HIPCHK(hipStreamSynchronize(s));
+                out.wide_root_without_big = out.n_wnodes;
+                break;
+            }
     }
     return "";
 }

@@ -107,6 +107,11 @@ struct DevScene {
     // not REF_EMPTY_WORD: the one-ray-per-round kernels test every sphere (one or two) for every ray up front and start the
     // traversal at this reference, the part of the hierarchy that holds everything else
     uint32_t spheres_first_root;
+    // big_count != 0: the scene's (at most three) large triangles, slots big_first ..., sit in a leaf of their own under the root;
+    // k_surface marks the rays it makes that can hit none of them (the first half of the triangle test fails for each), and the
+    // deferred-test kernels start such a ray at the root of the hierarchy without that leaf (big_root_bin in `nodes`,
+    // big_root_wide in `wnodes`; REF_EMPTY_WORD: that form has none)
+    uint32_t big_first, big_count, big_root_bin, big_root_wide;
     // lights
     const PtcPointLight* plights;
     const PtcDirectionalLight* dlights;
@@ -136,6 +141,10 @@ struct RenderParams {
     int32_t brute_force;
     uint32_t samples_per_path;  // shadow-ray samples per segment (integrator dependent)
     uint32_t group_hits;        // group the hits of a bounce by shading class (mixed scenes)
+    // k_surface marks the rays it makes that can hit none of the scene's large triangles (DevScene::big_count): their planes,
+    // (normal, first vertex), equal ones once; 0 planes = no marking
+    uint32_t n_big_planes;
+    float big_plane[3][6];
     uint32_t root_light_samples;
     // traversal tuning: idle lanes that trigger a refill, 0 = one ray per thread, 1 = refilling waves + while-while rounds, 2 = refilling waves + single steps,
     // entries a wave reserves per atomic (0 = chosen from the launch size)

@@ -16,6 +16,27 @@ struct Cand {
     float t, u, v;
 };
 
+// The first half of the triangle test (Triangle.cu:15-30): the distance to the triangle's plane, and whether it can still be a hit (not
+// parallel, in front, inside [t_lo, t_hi] and not below the source's 0.001).  tri_candidate goes on from here; the
+// deferred-test kernels run this half alone on the scene's large triangles to decide whether a full test is worth queueing.
+__device__ __forceinline__ bool tri_plane_distance(vec3 n0, vec3 v1, vec3 o, vec3 d, float t_lo, float t_hi, float& t) {
+    // The source flips the normal when dot(d, n) >= 0 and then forms dot(n, -d), dot(v1 - o, n) and dot(d, n) with
+    // the flipped normal.  Negating one factor of every product negates the rounded sum exactly, so these are
+    // -|dot(d, n0)|... with the same bits: nothing is recomputed, and the early exits are one test each side of
+    // the division instead of a chain of branches.
+    const float dn = dot(d, n0);
+    const bool flip = dn >= .0f;
+    const float den = flip ? -dn : dn;                 // dot(d, n) = -dot(n, -d): <= 0 or NaN
+    const float num0 = dot(v1 - o, n0);
+    const float num = flip ? -num0 : num0;             // dot(v1 - o, n)
+    // nDotWo == 0 is den == 0; a positive numerator over the negative denominator rounds to a value <= -0 < 0.001
+    if ((den == 0.0f) | (num > 0.f)) return false;
+    t = num / den;
+    // `t < 0.001` is a double comparison in the source; 0.001f is the smallest float above the double 0.001, so
+    // the float comparison is equivalent (a NaN passes it in the source and fails the interval test here as there)
+    return (t >= 0.001f) & (t > t_lo) & (t <= t_hi);
+}
+
 // Triangle.cu:15-46.  q0=(v1,n.x) q1=(v2,n.y) q2=(v3,n.z).
 // [t_lo, t_hi] is the interval outside of which the caller discards the candidate
 // anyway (tmin < t < tmax, and t <= current closest distance): the barycentric part
@@ -27,22 +48,9 @@ __device__ __forceinline__ Cand tri_candidate(float4 q0, float4 q1, float4 q2, v
     c.t = c.u = c.v = 0.f;
     const vec3 n0 = mk3(q0.w, q1.w, q2.w);
     vec3 v1 = mk3(q0.x, q0.y, q0.z), v2 = mk3(q1.x, q1.y, q1.z), v3 = mk3(q2.x, q2.y, q2.z);
-    // The source flips the normal when dot(d, n) >= 0 and then forms dot(n, -d), dot(v1 - o, n) and dot(d, n) with
-    // the flipped normal.  Negating one factor of every product negates the rounded sum exactly, so these are
-    // -|dot(d, n0)|... with the same bits: nothing is recomputed, and the early exits are one test each side of
-    // the division instead of a chain of branches.
-    const float dn = dot(d, n0);
-    const bool flip = dn >= .0f;
-    const float den = flip ? -dn : dn;                 // dot(d, n) = -dot(n, -d): <= 0 or NaN
-    const float num0 = dot(v1 - o, n0);
-    const float num = flip ? -num0 : num0;             // dot(v1 - o, n)
-    // nDotWo == 0 is den == 0; a positive numerator over the negative denominator rounds to a value <= -0 < 0.001
-    if ((den == 0.0f) | (num > 0.f)) return c;
-    const float t = num / den;
+    float t;
+    if (!tri_plane_distance(n0, v1, o, d, t_lo, t_hi, t)) return c;
     const vec3 P = o + t * d;
-    // `t < 0.001` is a double comparison in the source; 0.001f is the smallest float above the double 0.001, so
-    // the float comparison is equivalent (a NaN passes it in the source and fails the interval test here as there)
-    if (!((t >= 0.001f) & (t > t_lo) & (t <= t_hi))) return c;
     vec3 tmp0 = v3 - v1, tmp1 = v2 - v1, tmp2 = P - v1;
     float d00 = dot(tmp0, tmp0), d01 = dot(tmp0, tmp1), d02 = dot(tmp0, tmp2);
     float d11 = dot(tmp1, tmp1), d12 = dot(tmp1, tmp2);

@@ -22,6 +22,10 @@
 #include "ptcore.h"
 #include "wavefront.h"
 
+#ifndef BIG_FIRST_OFF
+#define BIG_FIRST_OFF 0   /* 1: no ray is marked as unable to hit the large triangles (A/B builds) */
+#endif
+
 // Device memory of ptc_render_range_static: the per-path arrays of a batch and the two per-pixel seed
 // arrays live here instead of in allocations.  Every GPU the library runs on holds its own copy of the
 // array at its own address; host code only ever uses the address hipGetSymbolAddress returned for the
@@ -76,6 +80,7 @@ struct ptc_context {
     bool non_diffuse = false;
     bool group_hits = false;                    // PTC_OPT_GROUP_HITS
     bool dense_surface = true;                  // PTC_OPT_DENSE_SURFACE
+    bool mark_rays = true;                      // PTC_OPT_MARK_RAYS
     float hit_ratio[16] = {0.f};                // hits per live path in the last batch: [0] camera rays, [b + 1] bounce b of later segments (0 = not known yet)
     bool mixed_hits = false;                    // hits fall into more than one shading class (primitive kind x BRDF)
 
@@ -329,6 +334,14 @@ void collectSpans(ptc_context* c) {  // stream must be idle
     c->ev_used = 0;
 }
 
+// Which root the deferred-test kernels start at when they test the large triangles up front (see DevScene::big_count).
+void setBigFirst(DevScene& sc, const BvhBuildOutput& b) {
+    sc.big_count = b.big_count;
+    sc.big_first = b.big_first;
+    sc.big_root_bin = b.root_without_big;
+    sc.big_root_wide = b.wnodes ? b.wide_root_without_big : REF_EMPTY_WORD;
+}
+
 DevScene deviceScene(const ptc_context* c) {
     DevScene sc{};
     sc.tri_q = c->bvh.tri_q;
@@ -353,6 +366,7 @@ DevScene deviceScene(const ptc_context* c) {
     sc.n_dlights = (uint32_t)c->dlights.size();
     sc.n_qlights = (uint32_t)c->qlights.size();
     sc.spheres_first_root = c->bvh.root_without_spheres;
+    setBigFirst(sc, c->bvh);
     return sc;
 }
 
@@ -373,6 +387,7 @@ DevScene deviceSceneAny(const ptc_context* c) {
     sc.n_wnodes = c->bvh_any.n_wnodes;
     sc.n_nodes = c->bvh_any.n_nodes;
     sc.spheres_first_root = c->bvh_any.root_without_spheres;
+    setBigFirst(sc, c->bvh_any);
     return sc;
 }
 
@@ -407,6 +422,23 @@ int makeParams(ptc_context* ctx, int frame_id, uint32_t w, uint32_t h, RenderPar
     rp.root_light_samples = (uint32_t)(int)sqrtf((float)ctx->light_samples);
     rp.samples_per_path = samplesPerSegment(ctx, rp.root_light_samples);
     rp.group_hits = ctx->mixed_hits && ctx->group_hits ? 1 : 0;
+    // rays marked "cannot hit the large triangles": only when both hierarchies keep the same large triangles apart
+    rp.n_big_planes = 0;
+    std::memset(rp.big_plane, 0, sizeof(rp.big_plane));
+    if (!BIG_FIRST_OFF && ctx->mark_rays && ctx->bvh.big_count != 0u && (!ctx->two_trees || ctx->bvh_any.big_count == ctx->bvh.big_count)) {
+        for (uint32_t k = 0; k < ctx->bvh.big_count && k < 3u; ++k) {
+            const int32_t g = ctx->bvh.big_prim[k];
+            if (g < 0 || (size_t)g >= ctx->tris.size()) {  // (cannot happen: then nothing is marked)
+                rp.n_big_planes = 0;
+                break;
+            }
+            const PtcTriangle& t = ctx->tris[(size_t)g];
+            const float pl[6] = {t.normal.x, t.normal.y, t.normal.z, t.v1.x, t.v1.y, t.v1.z};
+            bool seen = false;
+            for (uint32_t j = 0; j < rp.n_big_planes; ++j) seen = seen || std::memcmp(rp.big_plane[j], pl, sizeof(pl)) == 0;
+            if (!seen) std::memcpy(rp.big_plane[rp.n_big_planes++], pl, sizeof(pl));
+        }
+    }
     rp.tune_refill = ctx->tune_refill;
     rp.tune_mode = ctx->tune_mode;
     // shadow rays end at very different times (any hit stops them): refilling waves pay off
@@ -1181,6 +1213,7 @@ int ptc_probe_segments(ptc_context* ctx, uint32_t n, const PtcSegmentProbe* in, 
     rp.seeding = 1;  // leaves the per-pixel segment counters alone
     rp.cull_zero = 0;
     rp.bounce_cap = 0xFFFFFFFFu;
+    rp.n_big_planes = 0;  // (the depth word of a survivor is reported as it is stored)
     const uint32_t S = rp.samples_per_path;
     const uint32_t cap = (n + 4095u) & ~4095u;
     rc = ensureTargets(ctx, ctx->width ? ctx->width : 64, ctx->height ? ctx->height : 64);  // segctr / acc exist
@@ -1310,6 +1343,7 @@ int ptc_set_option(ptc_context* ctx, int option, int64_t value) try {
         case PTC_OPT_OVERLAP_GATHER: ctx->overlap_gather = value != 0; break;
         case PTC_OPT_SORT_RAYS: ctx->sort_rays = value != 0; break;
         case PTC_OPT_DENSE_SURFACE: ctx->dense_surface = value != 0; break;
+        case PTC_OPT_MARK_RAYS: ctx->mark_rays = value != 0; break;
         case PTC_OPT_BVH_BUILDER:
             if (value < 0 || value > 4) return fail(ctx, PTC_ERR_INVALID, "BVH builder must be 0 (LBVH), 1 (PLOC), 2 (surface-area sweep on the host), 4 (the same sweep on the GPU) or 3 (4 for closest-hit rays, 1 for any-hit rays)");
             ctx->bvh_builder = (int)value;

@@ -85,6 +85,12 @@ struct BvhBuildOutput {  // device allocations owned by the caller afterwards
     // A scene with one or two spheres beside its triangles (the Cornell boxes): the reference of the rest of the
     // hierarchy, so that every ray can test the spheres first and then traverse without them; REF_EMPTY_WORD otherwise.
     uint32_t root_without_spheres = REF_EMPTY_WORD;
+    // The large triangles of the scene (at most three, in one leaf under the root) can be tested for every ray up front: their
+    // slots, and where the traversal starts without them -- in the two-box nodes and in the four-wide nodes (an extra node after
+    // the hierarchy's own: the root with that leaf's child slot emptied).  big_count = 0: not available.
+    uint32_t big_first = 0, big_count = 0;
+    int32_t big_prim[3] = {-1, -1, -1};  // their global triangle indices
+    uint32_t root_without_big = REF_EMPTY_WORD, wide_root_without_big = REF_EMPTY_WORD;
     double host_ms = 0.0;        // wall-clock time of the build's passes over primitives / nodes that ran in host code
 };
 

@@ -281,14 +281,33 @@ __device__ __forceinline__ uint32_t segment_seed(const RenderParams& rp, uint32_
 
 // (origin | seed) and (direction | depth) of the segment at position `at` of the path state.  Camera segments all
 // start at the eye with depth 0, so k_generate writes one record per path for them, (direction | seed), and not two.
-__device__ __forceinline__ void load_segment(const RenderParams& rp, const PathState& ps, uint32_t at, float4& o4, float4& d4) {
+// A ray can carry one bit from the kernel that made it to the kernel that traces it: "none of the scene's large triangles
+// (DevScene::big_count) can be hit" -- k_surface has run the first half of the triangle test on them.  Later segments: the top
+// bit of the depth word; shadow rays: the sign of the stored tmax (a tmax that is not positive is stored as +0: nothing lies
+// in (tmin, tmax) either way).  The loaders below take the bit out, so every other reader sees plain values.
+#define SEG_SKIP_BIG 0x80000000u
+__device__ __forceinline__ void load_segment(const RenderParams& rp, const PathState& ps, uint32_t at, float4& o4, float4& d4, bool* skip_big = nullptr) {
     d4 = ps.d_depth[at];
     if (rp.camera_rays) {
         o4 = make_float4(rp.cf.eye.x, rp.cf.eye.y, rp.cf.eye.z, d4.w);
         d4.w = u2f(0u);
+        if (skip_big) *skip_big = false;
     } else {
         o4 = ps.o_seed[at];
+        if (skip_big) *skip_big = (f2u(d4.w) & SEG_SKIP_BIG) != 0u;
+        d4.w = u2f(f2u(d4.w) & ~SEG_SKIP_BIG);
     }
+}
+// Shadow ray idx: o4 = (origin | tmax), d4 = (direction | slot of the ray's term).
+__device__ __forceinline__ void load_shadow_ray(const PathState& ps, uint32_t idx, float4& o4, float4& d4, bool* skip_big = nullptr) {
+    o4 = ps.sh_o[idx];
+    d4 = ps.sh_d[idx];
+    if (skip_big) *skip_big = (f2u(o4.w) & 0x80000000u) != 0u;
+    o4.w = fabsf(o4.w);
+}
+__device__ __forceinline__ float shadow_tmax_word(float tmax, bool skip_big) {
+    const float t = tmax > 0.f ? tmax : (tmax != tmax ? tmax : 0.f);  // NaN stays NaN (such a ray accepts nothing wherever it starts)
+    return skip_big ? -t : t;
 }
 
 // ---------------------------------------------------------------- generate --
@@ -538,7 +557,8 @@ __global__ __launch_bounds__(BLOCK) void k_shadow_static(RenderParams rp, DevSce
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i == 0) atomicAdd(shadow_total, (unsigned long long)count);
     if (i >= count) return;
-    const float4 o4 = ps.sh_o[i], d4 = ps.sh_d[i];
+    float4 o4, d4;
+    load_shadow_ray(ps, i, o4, d4);
     ClosestHit tmp;
     TravCounters cnt = {0u, 0u};
     if (traverse_simple<true, COUNT>(sc, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), rp.cf.epsilon, o4.w, stack + threadIdx.x, tmp, cnt)) {
@@ -624,6 +644,9 @@ __device__ __forceinline__ void deferred_item(const DevScene& sc, DeferredLds& L
     if (L.best[rt] == key) L.best_ref[rt] = sphere ? HIT_SPHERE(slot) : (int)slot;
 }
 
+#ifndef BIG_FIRST_OFF
+#define BIG_FIRST_OFF 0
+#endif
 #ifndef DQ_MIN_WAVES
 #define DQ_MIN_WAVES 6   /* waves per SIMD the register allocation aims at (LDS allows 6 blocks per CU) */
 #endif
@@ -695,18 +718,23 @@ __global__ __launch_bounds__(BLOCK, DQ_MIN_WAVES) void k_trace_deferred(RenderPa
                 const uint32_t idx = wave_fetch(w, !active, work_counter, wave_chunk, count);
                 if (idx != 0xFFFFFFFFu) {
                     float4 o4, d4;
+                    bool skip_big;
                     if (ANY) {
-                        o4 = ps.sh_o[idx];
-                        d4 = ps.sh_d[idx];
+                        load_shadow_ray(ps, idx, o4, d4, &skip_big);
                         p = f2u(d4.w);   // slot of the ray's term
                         d4.w = o4.w;     // tmax
                     } else {
                         p = idx;
-                        load_segment(rp, ps, p, o4, d4);
+                        load_segment(rp, ps, p, o4, d4, &skip_big);
                         d4.w = PT_RAY_MAX;
                     }
                     o4.w = rp.cf.epsilon;
                     active = trav_init(sc, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), o4.w, d4.w, r, sp, cur, unused);
+                    // The scene's large triangles (a floor under a mesh) sit in a leaf of their own under the root, whose box every
+                    // ray that starts on the floor is inside of.  A ray that k_surface has marked -- the first half of the triangle
+                    // test fails for all of them: it leaves the floor, or points away from it -- starts at the root without that leaf.
+                    const uint32_t big_root = WIDE ? sc.big_root_wide : sc.big_root_bin;
+                    if (!BIG_FIRST_OFF && skip_big && big_root != REF_EMPTY_WORD) cur = big_root;
                     if (active) {
                         L.ray[0][tid] = make_float2(o4.x, o4.y);
                         L.ray[1][tid] = make_float2(o4.z, d4.x);
@@ -1083,7 +1111,8 @@ __global__ __launch_bounds__(BLOCK) void k_shadow(RenderParams rp, DevScene sc_g
         if (nidle >= rp.tune_refill && !(w.drained && w.pos >= w.end)) {
             const uint32_t idx = wave_fetch(w, !active, work_counter, wave_chunk, count);
             if (idx != 0xFFFFFFFFu) {
-                const float4 o4 = ps.sh_o[idx], d4 = ps.sh_d[idx];
+                float4 o4, d4;
+                load_shadow_ray(ps, idx, o4, d4);
                 slot = f2u(d4.w);
                 active = trav_init(sc, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), rp.cf.epsilon, o4.w, r, sp, cur, best);
                 if (SPHERES_FIRST && active) {  // see k_extend
@@ -1126,7 +1155,8 @@ __global__ __launch_bounds__(BLOCK) void k_shadow_brute(RenderParams rp, DevScen
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i == 0) atomicAdd(shadow_total, (unsigned long long)count);
     if (i >= count) return;
-    const float4 o4 = ps.sh_o[i], d4 = ps.sh_d[i];
+    float4 o4, d4;
+    load_shadow_ray(ps, i, o4, d4);
     ClosestHit tmp;
     if (brute_force<true>(sc, mk3(o4.x, o4.y, o4.z), mk3(d4.x, d4.y, d4.z), rp.cf.epsilon, o4.w, tmp)) {
         const uint32_t slot = f2u(d4.w);
@@ -1532,6 +1562,26 @@ __device__ __forceinline__ vec3 gather_radiance(const RenderParams& rp, const De
 #define MAT_WORDS (sizeof(PtcMaterialValue) / 4u)
 #define QLIGHT_LDS_MAX 8u   /* the quad lights travel with the materials: their corners are read once per light sample */
 #define QLIGHT_WORDS (sizeof(PtcQuadLight) / 4u)
+// Can the ray hit none of the scene's large triangles?  Their planes -- (normal, first vertex), equal ones once -- come with the
+// launch parameters.  The first exits of the triangle test in the test's own arithmetic (same products, same sums, so the
+// same signs): parallel to the plane, or the plane behind the origin; and, instead of the division, |num| < 0.0009 |den|,
+// which puts the quotient safely below the 0.001 under which the test rejects.  A ray for which every plane says "no" is
+// marked (SEG_SKIP_BIG) and the traversal kernels do not look at those triangles for it; any other ray is tested in full as before.
+__device__ __forceinline__ bool misses_big(const RenderParams& rp, vec3 o, vec3 d) {
+    bool any = false;
+    for (uint32_t k = 0; k < rp.n_big_planes; ++k) {
+        const vec3 n0 = mk3(rp.big_plane[k][0], rp.big_plane[k][1], rp.big_plane[k][2]);
+        const vec3 v1 = mk3(rp.big_plane[k][3], rp.big_plane[k][4], rp.big_plane[k][5]);
+        const float dn = dot(d, n0);
+        const bool flip = dn >= .0f;
+        const float den = flip ? -dn : dn;
+        const float num0 = dot(v1 - o, n0);
+        const float num = flip ? -num0 : num0;
+        const bool no = (den == 0.0f) | (num > 0.f) | (fabsf(num) < 0.0009f * fabsf(den));
+        any = any || !no;
+    }
+    return rp.n_big_planes != 0u && !any;
+}
 // FAST: the shading arithmetic takes the hardware's reciprocal / square root / reciprocal square root (ShMath); the
 // path tracer under `intended` semantics only.
 template <int INTEG, bool MATS = false, bool FAST = false>
@@ -1657,7 +1707,7 @@ __global__ __launch_bounds__(SURF_BLOCK_MANY, FAST ? SURF_WAVES : SURF_WAVES_EXA
 #pragma unroll
                 for (uint32_t k = 0; k < MANY_STEP; ++k) {
                     if (need_ray[k]) {
-                        ps.sh_o[at_[k]] = make_float4(sh_o[k].x, sh_o[k].y, sh_o[k].z, sh_tmax[k]);
+                        ps.sh_o[at_[k]] = make_float4(sh_o[k].x, sh_o[k].y, sh_o[k].z, shadow_tmax_word(sh_tmax[k], false));
                         ps.sh_d[at_[k]] = make_float4(sh_d[k].x, sh_d[k].y, sh_d[k].z, u2f(slot[k]));
                     }
                 }
@@ -1718,7 +1768,8 @@ __global__ __launch_bounds__(SURF_BLOCK_MANY, FAST ? SURF_WAVES : SURF_WAVES_EXA
         const uint32_t key0 = (x * rp.height + y) * rp.frame_id;
         const uint32_t seed = segment_seed(rp, key0, sample, bounce, segctr, pix);
         n_o = make_float4(sg.o.x, sg.o.y, sg.o.z, u2f(seed));
-        n_d = make_float4(sg.d.x, sg.d.y, sg.d.z, u2f(sg.depth));
+        const bool skip_big = misses_big(rp, sg.o, sg.d);
+        n_d = make_float4(sg.d.x, sg.d.y, sg.d.z, u2f(sg.depth | (skip_big ? SEG_SKIP_BIG : 0u)));
         n_t = make_float4(sg.thr.x, sg.thr.y, sg.thr.z, u2f(p));
     }
     uint32_t next_at = 0;  // the survivor's position in the next bounce's (packed) path state
@@ -1728,7 +1779,8 @@ __global__ __launch_bounds__(SURF_BLOCK_MANY, FAST ? SURF_WAVES : SURF_WAVES_EXA
 #pragma unroll
         for (uint32_t q = 0; q < 2u; ++q)
             if (f_need[q]) {
-                ps.sh_o[pos[q]] = make_float4(f_o[q].x, f_o[q].y, f_o[q].z, f_tmax[q]);
+                const bool skip_big = misses_big(rp, f_o[q], f_d[q]);
+                ps.sh_o[pos[q]] = make_float4(f_o[q].x, f_o[q].y, f_o[q].z, shadow_tmax_word(f_tmax[q], skip_big));
                 ps.sh_d[pos[q]] = make_float4(f_d[q].x, f_d[q].y, f_d[q].z, u2f(f_slot[q]));
             }
         if (gather) gather_queue[pos[2]] = i;
