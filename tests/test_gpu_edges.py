@@ -309,6 +309,69 @@ def test_random_soups_against_brute_force(case, builder):
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), hex(tune)
 
 
+@pytest.mark.parametrize("n_big,tilt,eye_height", [(1, 0.0, 0.3), (2, 0.0, 0.02), (2, 0.37, 0.3), (3, 0.0, 1e-3), (4, 0.0, 0.3)])
+@pytest.mark.parametrize("integrator", ["pathtracer", "direct"])
+def test_marked_rays_over_large_triangles(n_big, tilt, eye_height, integrator):
+    """A cloud of 3000 small triangles over a floor of 1-4 triangles a thousand times their size (with one to three of
+    them the surface kernel marks the rays that cannot hit the floor and the traversal starts those below the floor's
+    leaf; four are too many and go the ordinary way), the floor level or tilted, the camera well above it or a hair
+    above it so that most rays graze it, a quad light overhead: hits, sums and ray counts equal brute force over all
+    primitives bit for bit, for both hierarchies and with the marks off as well."""
+    rng = np.random.default_rng(40 + n_big)
+    n_small = 3000
+    lines = ["size 96 72", f"integrator {integrator}", "spp 4", "maxdepth 4", "nexteventestimation on", "russianroulette on", "importancesampling brdf",
+             f"camera 0 {eye_height} 2.5 0 0.2 0 0 1 0 60", "quadLight -0.5 3 -0.5 0 0 1 1 0 0 9 9 9", f"maxverts {3 * n_small + 8}", "diffuse 0.5 0.5 0.5",
+             "specular 0.2 0.2 0.2", "shininess 10"]
+    verts, tris = [], []
+    for i in range(n_small):
+        c = rng.uniform(-1.5, 1.5, 3) * np.array([1, 0.5, 1]) + np.array([0, 0.8, 0])
+        for _ in range(3):
+            v = c + rng.uniform(-0.05, 0.05, 3)
+            verts.append(f"vertex {v[0]:.5f} {v[1]:.5f} {v[2]:.5f}")
+        tris.append(f"tri {3 * i} {3 * i + 1} {3 * i + 2}")
+    base = 3 * n_small
+    e = 60.0
+    corners = [(-e, -e), (e, -e), (e, e), (-e, e), (0.0, 0.0)]
+    for x, z in corners:
+        verts.append(f"vertex {x} {tilt * x / e:.6f} {z}")
+    if n_big <= 2:
+        floor = [(0, 1, 2), (0, 2, 3)][:n_big]
+    elif n_big == 3:
+        floor = [(0, 1, 4), (1, 2, 4), (2, 3, 0)]
+    else:
+        floor = [(0, 1, 4), (1, 2, 4), (2, 3, 4), (3, 0, 4)]
+    tris += [f"tri {base + a} {base + c} {base + b}" for a, b, c in floor]  # facing up
+    scene = SceneLoader().loadText("\n".join(lines + verts + tris) + "\n")
+    b = Renderer(scene, options={_ffi.OPT_BRUTE_FORCE: 1, _ffi.OPT_SEEDING: 1, _ffi.OPT_SEMANTICS: 1})
+    want_hits = b.primary_hits()
+    b.run()
+    want, want_rays = b.sums().copy(), (b.stats().extension_rays, b.stats().shadow_rays)
+    b.close()
+    assert (want_hits["prim"] >= 3000).mean() > 0.03 and want_rays[1] > 0  # the floor is seen, shadow rays are traced
+    tests = {}
+    for builder in (3, 1):
+        for mark in (1, 0):
+            r = Renderer(scene, options={_ffi.OPT_SEEDING: 1, _ffi.OPT_SEMANTICS: 1, _ffi.OPT_BVH_BUILDER: builder, _ffi.OPT_MARK_RAYS: mark,
+                                         _ffi.OPT_COUNT_TRAVERSAL: 1, _ffi.OPT_TUNE_TRAVERSAL: 0x6620})
+            hits = r.primary_hits()
+            r.reset_stats()
+            r.run()
+            st = r.stats()
+            got = r.sums()
+            r.close()
+            for f in ("prim", "t", "u", "v"):
+                assert np.array_equal(hits[f].view(np.uint32), want_hits[f].view(np.uint32)), (builder, mark, f)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (builder, mark)
+            assert (st.extension_rays, st.shadow_rays) == want_rays, (builder, mark)
+            tests[builder, mark] = st.prims_tested + st.shadow_prims_tested
+        # the marks save triangle tests where they apply (the counts vary by a few in ten thousand from run to run: which queued
+        # test sees which closest distance depends on the order in which the waves' batches run)
+        if n_big <= 3:
+            assert tests[builder, 1] < 0.995 * tests[builder, 0], tests
+        else:
+            assert abs(tests[builder, 1] - tests[builder, 0]) < 0.01 * tests[builder, 0], tests
+
+
 @pytest.mark.parametrize("n_tris,n_spheres", [(1, 0), (0, 1), (7, 1), (24, 1), (30, 0), (12, 6), (3, 9), (36, 2), (60, 6), (12, 21), (100, 40), (190, 0), (400, 0)])
 def test_small_scenes_against_brute_force(n_tris, n_spheres):
     """Scenes of a few dozen primitives: the refilling kernels traverse a copy of the hierarchy and the primitives
