@@ -612,10 +612,10 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 // One queued primitive test.  `rt` = block-relative index of the ray's owner.
-template <bool ANY>
+template <bool ANY, bool SPH>
 __device__ __forceinline__ void deferred_item(const DevScene& sc, DeferredLds& L, uint32_t item, uint32_t wave_base, float tmin) {
     const uint32_t rt = wave_base + (item >> 26), slot = item & 0x1FFFFFFu;
-    const bool sphere = (item & 0x2000000u) != 0u;
+    const bool sphere = SPH && (item & 0x2000000u) != 0u;
     const float2 r0 = L.ray[0][rt], r1 = L.ray[1][rt], r2 = L.ray[2][rt];
     const vec3 o = mk3(r0.x, r0.y, r1.x), d = mk3(r1.y, r2.x, r2.y);
     if (ANY) {
@@ -650,7 +650,8 @@ __device__ __forceinline__ void deferred_item(const DevScene& sc, DeferredLds& L
 #ifndef DQ_MIN_WAVES
 #define DQ_MIN_WAVES 6   /* waves per SIMD the register allocation aims at (LDS allows 6 blocks per CU) */
 #endif
-template <bool ANY, bool COUNT, bool WIDE>
+// SPH = false: a scene without spheres -- the sphere test and its branches are compiled out (extension traversal -1.8 %, shadow -1 % on the dragon)
+template <bool ANY, bool COUNT, bool WIDE, bool SPH = true>
 __global__ __launch_bounds__(BLOCK, DQ_MIN_WAVES) void k_trace_deferred(RenderParams rp, DevScene sc, PathState ps,
                                                           const uint32_t* __restrict__ count_ptr, uint32_t count_arg,
                                                           uint32_t* __restrict__ work_counter, uint32_t wave_chunk,
@@ -694,7 +695,7 @@ __global__ __launch_bounds__(BLOCK, DQ_MIN_WAVES) void k_trace_deferred(RenderPa
                 }
                 if (lane < n) {
                     if (COUNT) cnt.prims++;
-                    deferred_item<ANY>(sc, L, items[qn - n + lane], wave_base, rp.cf.epsilon);
+                    deferred_item<ANY, SPH>(sc, L, items[qn - n + lane], wave_base, rp.cf.epsilon);
                 }
                 qn -= n;
                 wave_lds_sync();
@@ -772,7 +773,7 @@ __global__ __launch_bounds__(BLOCK, DQ_MIN_WAVES) void k_trace_deferred(RenderPa
                     cnt.prims++;
                     st_full++;
                 }
-                deferred_item<ANY>(sc, L, items[qn - 64u + lane], wave_base, rp.cf.epsilon);
+                deferred_item<ANY, SPH>(sc, L, items[qn - 64u + lane], wave_base, rp.cf.epsilon);
                 qn -= 64u;
             } while (qn >= 64u);
             wave_lds_sync();
@@ -818,7 +819,7 @@ __global__ __launch_bounds__(BLOCK, DQ_MIN_WAVES) void k_trace_deferred(RenderPa
         }
         // ---- leaves: queue their primitives, carry on with the stack
         const uint32_t kind = REF_KIND(cur);
-        const bool leaf = active && cur != REF_DONE && (kind == REF_TRI || kind == REF_SPHERE);
+        const bool leaf = active && cur != REF_DONE && (kind == REF_TRI || (SPH && kind == REF_SPHERE));
         if (COUNT) st_leaf += (uint32_t)__popcll(__ballot(leaf));
         if (__any(leaf)) {
             const uint32_t have = leaf ? REF_COUNT(cur) : 0u;
@@ -834,7 +835,7 @@ __global__ __launch_bounds__(BLOCK, DQ_MIN_WAVES) void k_trace_deferred(RenderPa
                 const uint32_t first = REF_FIRST(cur);
                 // predicated stores at fixed offsets (a loop over k becomes a loop with exec-mask bookkeeping per round)
                 uint32_t* dst = items + qn + pre;
-                const uint32_t item0 = DQ_ITEM(lane, kind == REF_SPHERE, first);
+                const uint32_t item0 = DQ_ITEM(lane, SPH && kind == REF_SPHERE, first);
                 dst[0] = item0;  // a leaf holds at least one primitive
 #pragma unroll
                 for (uint32_t k = 1; k < DQ_LEAF; ++k)
@@ -2023,6 +2024,8 @@ void wf_extend(hipStream_t s, const RenderParams& rp, const DevScene& sc, const 
         hipLaunchKernelGGL(k_extend_brute, dim3(blocks_for(count)), dim3(BLOCK), 0, s, rp, sc, ps, count);
     else if (mode == 4 && wide && count_trav)
         hipLaunchKernelGGL((k_trace_deferred<false, true, true>), dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, nullptr, count, work_counter, wave_chunk, trav_counters, nullptr);
+    else if (mode == 4 && wide && sc.n_spheres == 0u)
+        hipLaunchKernelGGL((k_trace_deferred<false, false, true, false>), dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, nullptr, count, work_counter, wave_chunk, trav_counters, nullptr);
     else if (mode == 4 && wide)
         hipLaunchKernelGGL((k_trace_deferred<false, false, true>), dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, nullptr, count, work_counter, wave_chunk, trav_counters, nullptr);
     else if (mode == 4 && count_trav)
@@ -2057,6 +2060,8 @@ void wf_shadow(hipStream_t s, const RenderParams& rp, const DevScene& sc, const 
         hipLaunchKernelGGL(k_shadow_brute, dim3(blocks_for(max_rays)), dim3(BLOCK), 0, s, rp, sc, ps, count_ptr, shadow_total);
     else if (smode == 4 && wide && count_trav)
         hipLaunchKernelGGL((k_trace_deferred<true, true, true>), dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, count_ptr, 0u, work_counter, wave_chunk, trav_counters, shadow_total);
+    else if (smode == 4 && wide && sc.n_spheres == 0u)
+        hipLaunchKernelGGL((k_trace_deferred<true, false, true, false>), dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, count_ptr, 0u, work_counter, wave_chunk, trav_counters, shadow_total);
     else if (smode == 4 && wide)
         hipLaunchKernelGGL((k_trace_deferred<true, false, true>), dim3(blocks), dim3(BLOCK), 0, s, rp, sc, ps, count_ptr, 0u, work_counter, wave_chunk, trav_counters, shadow_total);
     else if (smode == 4 && count_trav)
