@@ -115,8 +115,10 @@ struct HitAttr {
     uint32_t mat;  // material id | MAT_LIGHT_BIT
 };
 
+// SPH = false: the caller knows that the scene has no spheres (the sphere branch is compiled out)
+template <bool SPH = true>
 __device__ __forceinline__ void hit_attributes(const DevScene& sc, int ref, float t, vec3 o, vec3 d, HitAttr& a) {
-    if (ref >= 0) {  // Triangle.cu:48-58
+    if (!SPH || ref >= 0) {  // Triangle.cu:48-58
         const float4 nm = sc.tri_nm[ref];  // the stored normal and the material word: one record, the vertices are not needed here
         vec3 n = mk3(nm.x, nm.y, nm.z);
         if (dot(d, n) >= .0f) n = -n;

@@ -1585,7 +1585,8 @@ __device__ __forceinline__ bool misses_big(const RenderParams& rp, vec3 o, vec3 
 }
 // FAST: the shading arithmetic takes the hardware's reciprocal / square root / reciprocal square root (ShMath); the
 // path tracer under `intended` semantics only.
-template <int INTEG, bool MATS = false, bool FAST = false>
+// SPH = false: a scene without spheres (the sphere branch of the hit attributes is compiled out: -3 % on the dragon).
+template <int INTEG, bool MATS = false, bool FAST = false, bool SPH = true>
 __global__ __launch_bounds__(SURF_BLOCK_MANY, FAST ? SURF_WAVES : SURF_WAVES_EXACT) void k_surface(RenderParams rp, DevScene sc_global, PathState ps, const uint32_t* __restrict__ queue,
                                                        const uint32_t* __restrict__ count_ptr, uint32_t npix_pad, uint32_t sample_begin, uint32_t* __restrict__ segctr,
                                                        uint32_t* __restrict__ next_count,
@@ -1643,7 +1644,7 @@ __global__ __launch_bounds__(SURF_BLOCK_MANY, FAST ? SURF_WAVES : SURF_WAVES_EXA
         sg.depth = f2u(d4.w);
         sg.done = false;
         bounce = sg.depth;  // a live path has gained one unit of depth per segment (every integrator's survivors do `depth++` once)
-        hit_attributes(sc, hit_ref, ps.hit_t[at_state], sg.o, sg.d, at);
+        hit_attributes<SPH>(sc, hit_ref, ps.hit_t[at_state], sg.o, sg.d, at);
         sample = rp.samples_per_path != 0u && samples_lights<INTEG>(rp, at.mat, sg.depth);
     }
     if (in_range && !hit) {  // dense only: a miss ends the path: radiance = background colour (Common.cu:13-18), as k_compact_hits does
@@ -2138,8 +2139,8 @@ void wf_surface(hipStream_t s, const RenderParams& rp, const DevScene& sc, const
                            : rp.samples_per_path == 2u ? (fast ? SURF_BLOCK_BIG_TWO : SURF_BLOCK_BIG_TWO_EXACT) : SURF_BLOCK_BIG_ONE;
     const dim3 g(blocks_for(max_count, block)), b(block);
     const bool mats = !MAT_LDS_OFF && sc.n_materials != 0u && sc.n_materials <= MAT_LDS_MAX && sc.n_qlights <= QLIGHT_LDS_MAX;
-#define PT_SURFACE_LAUNCH(I, M, F)                                                                                                                            \
-    hipLaunchKernelGGL((k_surface<I, M, F>), g, b, 0, s, rp, sc, ps, queue, count_ptr, npix_pad, sample_begin, segctr, next_count, gather_queue, gather_count, \
+#define PT_SURFACE_LAUNCH(I, M, F, ...)                                                                                                                       \
+    hipLaunchKernelGGL((k_surface<I, M, F, ##__VA_ARGS__>), g, b, 0, s, rp, sc, ps, queue, count_ptr, npix_pad, sample_begin, segctr, next_count, gather_queue, gather_count, \
                        shadow_count, first_bounce ? 1u : 0u, max_count, block_tally)
 #define PT_SURFACE(I)                           \
     do {                                        \
@@ -2151,7 +2152,8 @@ void wf_surface(hipStream_t s, const RenderParams& rp, const DevScene& sc, const
         case INT_ANALYTICDIRECT: PT_SURFACE(INT_ANALYTICDIRECT); break;
         case INT_DIRECT: PT_SURFACE(INT_DIRECT); break;
         case INT_PATHTRACER:
-            if (fast && mats) PT_SURFACE_LAUNCH(INT_PATHTRACER, true, true);
+            if (fast && mats && sc.n_spheres == 0u) PT_SURFACE_LAUNCH(INT_PATHTRACER, true, true, false);
+            else if (fast && mats) PT_SURFACE_LAUNCH(INT_PATHTRACER, true, true);
             else if (fast) PT_SURFACE_LAUNCH(INT_PATHTRACER, false, true);
             else PT_SURFACE(INT_PATHTRACER);
             break;
