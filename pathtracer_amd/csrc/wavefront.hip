@@ -1586,7 +1586,10 @@ __device__ __forceinline__ bool misses_big(const RenderParams& rp, vec3 o, vec3 
 // FAST: the shading arithmetic takes the hardware's reciprocal / square root / reciprocal square root (ShMath); the
 // path tracer under `intended` semantics only.
 // SPH = false: a scene without spheres (the sphere branch of the hit attributes is compiled out: -3 % on the dragon).
-template <int INTEG, bool MATS = false, bool FAST = false, bool SPH = true>
+// MARK: the scene has large triangles whose planes come with the launch parameters, and the rays made here are tested against
+// them (misses_big).  A template parameter and not a run-time test of the plane count: with the code merely present the kernel is
+// 5-14 % slower on scenes that have no such triangles (the Cornell boxes).
+template <int INTEG, bool MATS = false, bool FAST = false, bool SPH = true, bool MARK = false>
 __global__ __launch_bounds__(SURF_BLOCK_MANY, FAST ? SURF_WAVES : SURF_WAVES_EXACT) void k_surface(RenderParams rp, DevScene sc_global, PathState ps, const uint32_t* __restrict__ queue,
                                                        const uint32_t* __restrict__ count_ptr, uint32_t npix_pad, uint32_t sample_begin, uint32_t* __restrict__ segctr,
                                                        uint32_t* __restrict__ next_count,
@@ -1770,7 +1773,7 @@ __global__ __launch_bounds__(SURF_BLOCK_MANY, FAST ? SURF_WAVES : SURF_WAVES_EXA
         const uint32_t key0 = (x * rp.height + y) * rp.frame_id;
         const uint32_t seed = segment_seed(rp, key0, sample, bounce, segctr, pix);
         n_o = make_float4(sg.o.x, sg.o.y, sg.o.z, u2f(seed));
-        const bool skip_big = misses_big(rp, sg.o, sg.d);
+        const bool skip_big = MARK && misses_big(rp, sg.o, sg.d);
         n_d = make_float4(sg.d.x, sg.d.y, sg.d.z, u2f(sg.depth | (skip_big ? SEG_SKIP_BIG : 0u)));
         n_t = make_float4(sg.thr.x, sg.thr.y, sg.thr.z, u2f(p));
     }
@@ -1781,7 +1784,7 @@ __global__ __launch_bounds__(SURF_BLOCK_MANY, FAST ? SURF_WAVES : SURF_WAVES_EXA
 #pragma unroll
         for (uint32_t q = 0; q < 2u; ++q)
             if (f_need[q]) {
-                const bool skip_big = misses_big(rp, f_o[q], f_d[q]);
+                const bool skip_big = MARK && misses_big(rp, f_o[q], f_d[q]);
                 ps.sh_o[pos[q]] = make_float4(f_o[q].x, f_o[q].y, f_o[q].z, shadow_tmax_word(f_tmax[q], skip_big));
                 ps.sh_d[pos[q]] = make_float4(f_d[q].x, f_d[q].y, f_d[q].z, u2f(f_slot[q]));
             }
@@ -2152,9 +2155,12 @@ void wf_surface(hipStream_t s, const RenderParams& rp, const DevScene& sc, const
         case INT_ANALYTICDIRECT: PT_SURFACE(INT_ANALYTICDIRECT); break;
         case INT_DIRECT: PT_SURFACE(INT_DIRECT); break;
         case INT_PATHTRACER:
-            if (fast && mats && sc.n_spheres == 0u) PT_SURFACE_LAUNCH(INT_PATHTRACER, true, true, false);
+            // (marked rays: scenes of triangles only, see misses_big)
+            if (fast && mats && rp.n_big_planes != 0u && sc.n_spheres == 0u) PT_SURFACE_LAUNCH(INT_PATHTRACER, true, true, false, true);
+            else if (fast && mats && sc.n_spheres == 0u) PT_SURFACE_LAUNCH(INT_PATHTRACER, true, true, false);
             else if (fast && mats) PT_SURFACE_LAUNCH(INT_PATHTRACER, true, true);
             else if (fast) PT_SURFACE_LAUNCH(INT_PATHTRACER, false, true);
+            else if (mats && rp.n_big_planes != 0u && sc.n_spheres == 0u) PT_SURFACE_LAUNCH(INT_PATHTRACER, true, false, false, true);
             else PT_SURFACE(INT_PATHTRACER);
             break;
         case INT_PATHTRACER2: PT_SURFACE(INT_PATHTRACER2); break;
