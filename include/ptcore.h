@@ -230,7 +230,8 @@ enum {
      * ray is made: the surface kernel runs the first exits of the triangle test against their planes for the shadow rays
      * and the next segment of every hit, and a ray that cannot hit any of them carries a mark with which the traversal
      * kernels start below that leaf.  The exits are the triangle test's own, so the same hits are found; a quarter of
-     * the dragon's shadow-ray triangle tests go away.  0 = no ray is marked.  Results do not depend on it. */
+     * the dragon's shadow-ray triangle tests go away.  Path tracer only, scenes of triangles with one to three such
+     * triangles.  0 = no ray is marked.  Results do not depend on it. */
     PTC_OPT_MARK_RAYS = 15
 };
 

@@ -366,7 +366,7 @@ def test_marked_rays_over_large_triangles(n_big, tilt, eye_height, integrator):
             tests[builder, mark] = st.prims_tested + st.shadow_prims_tested
         # the marks save triangle tests where they apply (the counts vary by a few in ten thousand from run to run: which queued
         # test sees which closest distance depends on the order in which the waves' batches run)
-        if n_big <= 3:
+        if n_big <= 3 and integrator == "pathtracer":  # (the marking variant of the surface kernel exists for the path tracer)
             assert tests[builder, 1] < 0.995 * tests[builder, 0], tests
         else:
             assert abs(tests[builder, 1] - tests[builder, 0]) < 0.01 * tests[builder, 0], tests
